@@ -1,0 +1,315 @@
+// Per-tile alpha compositing for gfx950, forward and backward.
+//
+// One 256-thread workgroup per 16x16 tile = 4 wave64; each wave owns one 8x8
+// pixel quadrant (one pixel per lane), so that a wave finishes, and skips
+// splats, on the evidence of its own 64 pixels only.  The tile's splat list is
+// consumed in batches of 256: every thread gathers one 64-byte splat record
+// (one cache line), tests it against the four quadrants with the splat's
+// alpha >= 1/255 bounding box, and publishes it to LDS together with a 64-bit
+// survivor mask per (quadrant, staging wave).  Each wave then walks only the
+// set bits of its own masks — scalar bit iteration, order preserved — and reads
+// the splat with LDS broadcast loads.  Splats that cannot reach any pixel of a
+// quadrant cost that wave nothing.
+#include "gsr_common.h"
+
+namespace {
+
+constexpr int kBatch = 256;
+constexpr float kLog2e = 1.4426950408889634f;
+
+struct Pixel {
+  int x, y;       // pixel coordinates
+  bool inside;    // inside the image
+  int quad;       // quadrant = wave index
+};
+
+__device__ __forceinline__ Pixel my_pixel(int W, int H) {
+  const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+  Pixel p;
+  p.quad = wave;
+  p.x = blockIdx.x * GSR_TILE_X + (wave & 1) * 8 + (lane & 7);
+  p.y = blockIdx.y * GSR_TILE_Y + (wave >> 1) * 8 + (lane >> 3);
+  p.inside = p.x < W && p.y < H;
+  return p;
+}
+
+// 4-bit mask: which 8x8 quadrants of the tile can see a splat centred at
+// (sx,sy) whose alpha >= 1/255 region spans +-hx, +-hy (negative = never).
+__device__ __forceinline__ unsigned quadrant_mask(float sx, float sy, float hx, float hy, float tx0, float ty0) {
+  if (hx < 0.0f) return 0u;
+  const float lx = sx - hx, rx = sx + hx, ly = sy - hy, ry = sy + hy;
+  const bool xl = (rx >= tx0) && (lx <= tx0 + 7.0f);
+  const bool xr = (rx >= tx0 + 8.0f) && (lx <= tx0 + 15.0f);
+  const bool yt = (ry >= ty0) && (ly <= ty0 + 7.0f);
+  const bool yb = (ry >= ty0 + 8.0f) && (ly <= ty0 + 15.0f);
+  return (unsigned)(xl && yt) | ((unsigned)(xr && yt) << 1) | ((unsigned)(xl && yb) << 2) | ((unsigned)(xr && yb) << 3);
+}
+
+__device__ __forceinline__ unsigned long long lds_mask(const unsigned long long* m) {
+  const unsigned long long v = *m;
+  const unsigned lo = __builtin_amdgcn_readfirstlane((unsigned)v);
+  const unsigned hi = __builtin_amdgcn_readfirstlane((unsigned)(v >> 32));
+  return ((unsigned long long)hi << 32) | lo;
+}
+
+// ---------------------------------------------------------------------------
+// forward
+// ---------------------------------------------------------------------------
+__global__ void __launch_bounds__(256) blend_fwd_kernel(int W, int H, const uint2* __restrict__ ranges,
+                                                        const uint32_t* __restrict__ point_list,
+                                                        const uint4* __restrict__ records,
+                                                        const float* __restrict__ bg, float* __restrict__ out_color,
+                                                        float* __restrict__ final_T, uint32_t* __restrict__ n_contrib) {
+  __shared__ float4 s_geo[kBatch];   // x, y, -A/2*log2e, -B*log2e
+  __shared__ float4 s_col[kBatch];   // -C/2*log2e, opacity, r, g
+  __shared__ float s_blue[kBatch];
+  __shared__ unsigned long long s_mask[4][4];  // [quadrant][staging wave]
+
+  const Pixel px = my_pixel(W, H);
+  const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+  const float pxf = (float)px.x, pyf = (float)px.y;
+  const float tx0 = (float)(blockIdx.x * GSR_TILE_X), ty0 = (float)(blockIdx.y * GSR_TILE_Y);
+  const uint2 range = ranges[blockIdx.y * gridDim.x + blockIdx.x];
+  const int total = (int)(range.y - range.x);
+  const int rounds = (total + kBatch - 1) / kBatch;
+
+  bool done = !px.inside;
+  float T = 1.0f, C0 = 0.f, C1 = 0.f, C2 = 0.f;
+  uint32_t last = 0;
+
+  for (int b = 0; b < rounds; b++) {
+    const bool wave_done = __ballot(!done) == 0ull;
+    if (__syncthreads_and(wave_done)) break;   // also fences the previous batch's LDS reads
+
+    // stage one batch
+    const int s = b * kBatch + (int)threadIdx.x;
+    unsigned qm = 0u;
+    if (s < total) {
+      const uint32_t g = point_list[range.x + s];
+      const uint4* rec = records + (size_t)g * 4;
+      const uint4 r0 = rec[0], r1 = rec[1], r2 = rec[2];
+      const float sx = __uint_as_float(r0.x), sy = __uint_as_float(r0.y);
+      qm = quadrant_mask(sx, sy, __uint_as_float(r0.z), __uint_as_float(r0.w), tx0, ty0);
+      s_geo[threadIdx.x] = make_float4(sx, sy, -0.5f * kLog2e * __uint_as_float(r1.x), -kLog2e * __uint_as_float(r1.y));
+      s_col[threadIdx.x] = make_float4(-0.5f * kLog2e * __uint_as_float(r1.z), __uint_as_float(r1.w),
+                                       __uint_as_float(r2.x), __uint_as_float(r2.y));
+      s_blue[threadIdx.x] = __uint_as_float(r2.z);
+    }
+#pragma unroll
+    for (int q = 0; q < 4; q++) {
+      const unsigned long long m = __ballot((qm >> q) & 1u);
+      if (lane == 0) s_mask[q][wave] = m;
+    }
+    __syncthreads();
+
+    if (!wave_done) {
+      for (int sw = 0; sw < 4; sw++) {
+        unsigned long long m = lds_mask(&s_mask[px.quad][sw]);
+        while (m) {
+          const int j = sw * 64 + (__ffsll((long long)m) - 1);
+          m &= m - 1;
+          const float4 ga = s_geo[j];
+          const float4 co = s_col[j];
+          const float dx = ga.x - pxf, dy = ga.y - pyf;
+          const float p = (ga.z * dx) * dx + (co.x * dy) * dy + (ga.w * dx) * dy;   // log2-domain exponent
+          if (!done && p <= 0.0f) {
+            const float alpha = fminf(GSR_ALPHA_MAX, co.y * __builtin_amdgcn_exp2f(p));
+            if (alpha >= GSR_ALPHA_MIN) {
+              const float test_T = T * (1.0f - alpha);
+              if (test_T < GSR_T_STOP) {
+                done = true;
+              } else {
+                const float w = alpha * T;
+                C0 += co.z * w;
+                C1 += co.w * w;
+                C2 += s_blue[j] * w;
+                T = test_T;
+                last = (uint32_t)(b * kBatch + j + 1);
+              }
+            }
+          }
+        }
+        if (__ballot(!done) == 0ull) break;
+      }
+    }
+  }
+
+  if (px.inside) {
+    const size_t pix = (size_t)px.y * W + px.x, plane = (size_t)W * H;
+    final_T[pix] = T;
+    n_contrib[pix] = last;
+    out_color[pix] = C0 + T * bg[0];
+    out_color[plane + pix] = C1 + T * bg[1];
+    out_color[2 * plane + pix] = C2 + T * bg[2];
+  }
+}
+
+// ---------------------------------------------------------------------------
+// backward
+// ---------------------------------------------------------------------------
+template <int CTRL, int ROW_MASK>
+__device__ __forceinline__ float dpp_add(float v) {
+  const int moved = __builtin_amdgcn_update_dpp(0, __float_as_int(v), CTRL, ROW_MASK, 0xf, false);
+  return v + __int_as_float(moved);
+}
+
+// Sum over the 64 lanes; the total is valid in lanes 48..63.
+__device__ __forceinline__ float wave_sum_hi(float v) {
+  v = dpp_add<0xB1, 0xf>(v);    // quad_perm [1,0,3,2]
+  v = dpp_add<0x4E, 0xf>(v);    // quad_perm [2,3,0,1]
+  v = dpp_add<0x141, 0xf>(v);   // row_half_mirror
+  v = dpp_add<0x140, 0xf>(v);   // row_mirror: every lane of a row holds the row sum
+  v = dpp_add<0x142, 0xa>(v);   // row_bcast:15 into rows 1 and 3
+  v = dpp_add<0x143, 0xc>(v);   // row_bcast:31 into rows 2 and 3
+  return v;
+}
+
+__global__ void __launch_bounds__(256) blend_bwd_kernel(int W, int H, const uint2* __restrict__ ranges,
+                                                        const uint32_t* __restrict__ point_list,
+                                                        const uint4* __restrict__ records,
+                                                        const float* __restrict__ bg,
+                                                        const float* __restrict__ final_T,
+                                                        const uint32_t* __restrict__ n_contrib,
+                                                        const float* __restrict__ dL_dpix,
+                                                        float* __restrict__ dL_dsplat) {
+  __shared__ float4 s_geo[kBatch];   // x, y, A, B
+  __shared__ float4 s_col[kBatch];   // C, opacity, r, g
+  __shared__ float s_blue[kBatch];
+  __shared__ uint32_t s_id[kBatch];
+  __shared__ unsigned long long s_mask[4][4];
+  __shared__ int s_last[4];
+
+  const Pixel px = my_pixel(W, H);
+  const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+  const float pxf = (float)px.x, pyf = (float)px.y;
+  const float tx0 = (float)(blockIdx.x * GSR_TILE_X), ty0 = (float)(blockIdx.y * GSR_TILE_Y);
+  const uint2 range = ranges[blockIdx.y * gridDim.x + blockIdx.x];
+  const int total = (int)(range.y - range.x);
+
+  const size_t pix = (size_t)px.y * W + px.x, plane = (size_t)W * H;
+  const float Tf = px.inside ? final_T[pix] : 0.f;
+  const int last = px.inside ? (int)n_contrib[pix] : 0;
+  float dp0 = 0.f, dp1 = 0.f, dp2 = 0.f;
+  if (px.inside) { dp0 = dL_dpix[pix]; dp1 = dL_dpix[plane + pix]; dp2 = dL_dpix[2 * plane + pix]; }
+  const float bg_dot = bg[0] * dp0 + bg[1] * dp1 + bg[2] * dp2;
+  const float ddelx_dx = 0.5f * (float)W, ddely_dy = 0.5f * (float)H;
+
+  // the tile starts at the deepest position any of its pixels used
+  int wl = last;
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) wl = max(wl, __shfl_xor(wl, o));
+  if (lane == 0) s_last[wave] = wl;
+  __syncthreads();
+  const int wave_last = wl;
+  const int tile_last = max(max(s_last[0], s_last[1]), max(s_last[2], s_last[3]));
+  if (tile_last == 0 || total == 0) return;
+
+  float T = Tf, acc0 = 0.f, acc1 = 0.f, acc2 = 0.f, lc0 = 0.f, lc1 = 0.f, lc2 = 0.f, last_alpha = 0.f;
+
+  for (int b = (tile_last - 1) / kBatch; b >= 0; b--) {
+    __syncthreads();
+    const int s = b * kBatch + (int)threadIdx.x;
+    unsigned qm = 0u;
+    if (s < total && s < tile_last) {
+      const uint32_t g = point_list[range.x + s];
+      const uint4* rec = records + (size_t)g * 4;
+      const uint4 r0 = rec[0], r1 = rec[1], r2 = rec[2];
+      const float sx = __uint_as_float(r0.x), sy = __uint_as_float(r0.y);
+      qm = quadrant_mask(sx, sy, __uint_as_float(r0.z), __uint_as_float(r0.w), tx0, ty0);
+      s_geo[threadIdx.x] = make_float4(sx, sy, __uint_as_float(r1.x), __uint_as_float(r1.y));
+      s_col[threadIdx.x] = make_float4(__uint_as_float(r1.z), __uint_as_float(r1.w), __uint_as_float(r2.x),
+                                       __uint_as_float(r2.y));
+      s_blue[threadIdx.x] = __uint_as_float(r2.z);
+      s_id[threadIdx.x] = g;
+    }
+#pragma unroll
+    for (int q = 0; q < 4; q++) {
+      const unsigned long long m = __ballot((qm >> q) & 1u);
+      if (lane == 0) s_mask[q][wave] = m;
+    }
+    __syncthreads();
+
+    if (b * kBatch >= wave_last) continue;   // nothing this deep for this quadrant
+    for (int sw = 3; sw >= 0; sw--) {
+      unsigned long long m = lds_mask(&s_mask[px.quad][sw]);
+      while (m) {
+        const int bit = 63 - __clzll((long long)m);
+        m &= ~(1ull << bit);
+        const int j = sw * 64 + bit;
+        const int pos = b * kBatch + j;   // 0-based position in the tile list
+        const float4 ga = s_geo[j];
+        const float4 co = s_col[j];
+        const float dx = ga.x - pxf, dy = ga.y - pyf;
+        const float power = -0.5f * (ga.z * dx * dx + co.x * dy * dy) - ga.w * dx * dy;
+        float g_mx = 0.f, g_my = 0.f, g_a = 0.f, g_b = 0.f, g_c = 0.f, g_o = 0.f, g_r = 0.f, g_g = 0.f, g_bl = 0.f;
+        bool hit = false;
+        if (pos < last && power <= 0.0f) {
+          const float G = __builtin_amdgcn_exp2f(power * kLog2e);
+          const float alpha = fminf(GSR_ALPHA_MAX, co.y * G);
+          if (alpha >= GSR_ALPHA_MIN) {
+            hit = true;
+            const float inv = __builtin_amdgcn_rcpf(1.0f - alpha);
+            T = T * inv;
+            const float dch = alpha * T;
+            const float blue = s_blue[j];
+            acc0 = last_alpha * lc0 + (1.0f - last_alpha) * acc0;
+            acc1 = last_alpha * lc1 + (1.0f - last_alpha) * acc1;
+            acc2 = last_alpha * lc2 + (1.0f - last_alpha) * acc2;
+            lc0 = co.z; lc1 = co.w; lc2 = blue;
+            float dL_dalpha = (co.z - acc0) * dp0 + (co.w - acc1) * dp1 + (blue - acc2) * dp2;
+            g_r = dch * dp0; g_g = dch * dp1; g_bl = dch * dp2;
+            dL_dalpha *= T;
+            last_alpha = alpha;
+            dL_dalpha += (-Tf * inv) * bg_dot;
+            const float dL_dG = co.y * dL_dalpha;
+            const float gdx = G * dx, gdy = G * dy;
+            const float dG_ddelx = -gdx * ga.z - gdy * ga.w;
+            const float dG_ddely = -gdy * co.x - gdx * ga.w;
+            g_mx = dL_dG * dG_ddelx * ddelx_dx;
+            g_my = dL_dG * dG_ddely * ddely_dy;
+            g_a = -0.5f * gdx * dx * dL_dG;
+            g_b = -gdx * dy * dL_dG;
+            g_c = -0.5f * gdy * dy * dL_dG;
+            g_o = G * dL_dalpha;
+          }
+        }
+        if (__ballot(hit) == 0ull) continue;
+        g_mx = wave_sum_hi(g_mx); g_my = wave_sum_hi(g_my);
+        g_a = wave_sum_hi(g_a); g_b = wave_sum_hi(g_b); g_c = wave_sum_hi(g_c);
+        g_o = wave_sum_hi(g_o);
+        g_r = wave_sum_hi(g_r); g_g = wave_sum_hi(g_g); g_bl = wave_sum_hi(g_bl);
+        if (lane == 63) {
+          float* dst = dL_dsplat + (size_t)s_id[j] * GSR_GRAD_WORDS;
+          atomicAdd(dst + 0, g_mx); atomicAdd(dst + 1, g_my);
+          atomicAdd(dst + 2, g_a); atomicAdd(dst + 3, g_b); atomicAdd(dst + 4, g_c);
+          atomicAdd(dst + 5, g_o);
+          atomicAdd(dst + 6, g_r); atomicAdd(dst + 7, g_g); atomicAdd(dst + 8, g_bl);
+        }
+      }
+    }
+  }
+}
+
+}  // namespace
+
+extern "C" int gsr_blend_fwd(int W, int H, const uint32_t* ranges, const uint32_t* point_list,
+                             const uint32_t* records, const float* bg, float* out_color, float* final_T,
+                             uint32_t* n_contrib, void* stream) {
+  GSR_REQUIRE(W > 0 && H > 0, "blend_fwd: bad image size %dx%d", W, H);
+  GSR_REQUIRE(ranges && bg && out_color && final_T && n_contrib, "blend_fwd: null pointer");
+  dim3 grid(gsr::div_up(W, GSR_TILE_X), gsr::div_up(H, GSR_TILE_Y)), block(256);
+  hipLaunchKernelGGL(blend_fwd_kernel, grid, block, 0, (hipStream_t)stream, W, H, (const uint2*)ranges, point_list,
+                     (const uint4*)records, bg, out_color, final_T, n_contrib);
+  return gsr::check_launch("blend_fwd");
+}
+
+extern "C" int gsr_blend_bwd(int W, int H, const uint32_t* ranges, const uint32_t* point_list,
+                             const uint32_t* records, const float* bg, const float* final_T,
+                             const uint32_t* n_contrib, const float* dL_dpix, float* dL_dsplat, void* stream) {
+  GSR_REQUIRE(W > 0 && H > 0, "blend_bwd: bad image size %dx%d", W, H);
+  GSR_REQUIRE(ranges && bg && final_T && n_contrib && dL_dpix && dL_dsplat, "blend_bwd: null pointer");
+  dim3 grid(gsr::div_up(W, GSR_TILE_X), gsr::div_up(H, GSR_TILE_Y)), block(256);
+  hipLaunchKernelGGL(blend_bwd_kernel, grid, block, 0, (hipStream_t)stream, W, H, (const uint2*)ranges, point_list,
+                     (const uint4*)records, bg, final_T, n_contrib, dL_dpix, dL_dsplat);
+  return gsr::check_launch("blend_bwd");
+}

@@ -1,0 +1,590 @@
+// Per-Gaussian stages of the rasterizer for gfx950: forward preprocess
+// (cull, project, covariance, EWA, conic, radius, tile rectangle, SH -> RGB)
+// and its backward.  One lane per Gaussian; both kernels are HBM-bound
+// (236 B in / ~80 B out per Gaussian forward at SH degree 3), so the work is
+// organised around wide loads and full-line stores, not arithmetic.
+//
+// This translation unit is compiled with -ffp-contract=off: every + - * / and
+// sqrt below is one IEEE-754 fp32 operation in the order written, so the
+// forward results (and with them radii, tile rectangles and sort keys) are
+// reproducible bit for bit by any IEEE implementation running the same
+// sequence — which is how the CPU oracle pins them.
+#include "gsr_common.h"
+
+namespace {
+
+constexpr int kBlock = 256;
+
+struct Vec3 { float x, y, z; };
+
+// [x y z 1] * M for a row-major (4,4) M: the reference stores its camera
+// matrices transposed and multiplies row vectors
+// (scene/cameras.py:54-56, utils/graphics_utils.py:22-29).
+__device__ __forceinline__ Vec3 xform43(const float* __restrict__ m, float x, float y, float z) {
+  Vec3 o;
+  o.x = m[0] * x + m[4] * y + m[8] * z + m[12];
+  o.y = m[1] * x + m[5] * y + m[9] * z + m[13];
+  o.z = m[2] * x + m[6] * y + m[10] * z + m[14];
+  return o;
+}
+
+// Rotation matrix of quaternion (w,x,y,z), taken as given (the reference
+// normalises in get_rotation before the call, scene/gaussian_model.py:100-101).
+__device__ __forceinline__ void quat_to_rot(float r, float x, float y, float z, float* R) {
+  R[0] = 1.0f - 2.0f * (y * y + z * z);
+  R[1] = 2.0f * (x * y - r * z);
+  R[2] = 2.0f * (x * z + r * y);
+  R[3] = 2.0f * (x * y + r * z);
+  R[4] = 1.0f - 2.0f * (x * x + z * z);
+  R[5] = 2.0f * (y * z - r * x);
+  R[6] = 2.0f * (x * z - r * y);
+  R[7] = 2.0f * (y * z + r * x);
+  R[8] = 1.0f - 2.0f * (x * x + y * y);
+}
+
+// Sigma = L L^T with L = R diag(mod * s), packed (xx,xy,xz,yy,yz,zz)
+// (Python twin: scene/gaussian_model.py:27-31, utils/general_utils.py:64-110).
+__device__ __forceinline__ void cov3d_from_scale_rot(const float* s, float mod, const float* q,
+                                                     float* c6) {
+  float R[9], L[9];
+  quat_to_rot(q[0], q[1], q[2], q[3], R);
+  const float sx = mod * s[0], sy = mod * s[1], sz = mod * s[2];
+#pragma unroll
+  for (int i = 0; i < 3; i++) {
+    L[3 * i + 0] = R[3 * i + 0] * sx;
+    L[3 * i + 1] = R[3 * i + 1] * sy;
+    L[3 * i + 2] = R[3 * i + 2] * sz;
+  }
+  c6[0] = L[0] * L[0] + L[1] * L[1] + L[2] * L[2];
+  c6[1] = L[0] * L[3] + L[1] * L[4] + L[2] * L[5];
+  c6[2] = L[0] * L[6] + L[1] * L[7] + L[2] * L[8];
+  c6[3] = L[3] * L[3] + L[4] * L[4] + L[5] * L[5];
+  c6[4] = L[3] * L[6] + L[4] * L[7] + L[5] * L[8];
+  c6[5] = L[6] * L[6] + L[7] * L[7] + L[8] * L[8];
+}
+
+struct Ewa {
+  float tx, ty, tz, xmul, ymul;
+  float M0[3], M1[3];
+  float a, b, c;
+};
+
+// EWA splatting: 2D covariance J W Sigma W^T J^T (+ dilation) of a Gaussian
+// whose view-space mean is pv.
+__device__ __forceinline__ void ewa_project(const float* __restrict__ V, int W, int H, float tanfovx,
+                                            float tanfovy, Vec3 pv, const float* c6, Ewa& e) {
+  const float fx = (float)W / (2.0f * tanfovx);
+  const float fy = (float)H / (2.0f * tanfovy);
+  const float limx = GSR_FRUSTUM_CLAMP * tanfovx;
+  const float limy = GSR_FRUSTUM_CLAMP * tanfovy;
+  const float tz = pv.z;
+  const float txtz = pv.x / tz, tytz = pv.y / tz;
+  e.xmul = (txtz < -limx || txtz > limx) ? 0.0f : 1.0f;
+  e.ymul = (tytz < -limy || tytz > limy) ? 0.0f : 1.0f;
+  const float tx = fminf(limx, fmaxf(-limx, txtz)) * tz;
+  const float ty = fminf(limy, fmaxf(-limy, tytz)) * tz;
+  e.tx = tx; e.ty = ty; e.tz = tz;
+  const float J00 = fx / tz, J02 = -(fx * tx) / (tz * tz);
+  const float J11 = fy / tz, J12 = -(fy * ty) / (tz * tz);
+#pragma unroll
+  for (int j = 0; j < 3; j++) {
+    const float W0 = V[4 * j + 0], W1 = V[4 * j + 1], W2 = V[4 * j + 2];
+    e.M0[j] = J00 * W0 + J02 * W2;
+    e.M1[j] = J11 * W1 + J12 * W2;
+  }
+  const float* M0 = e.M0;
+  const float* M1 = e.M1;
+  float v0[3], v1[3];
+  v0[0] = c6[0] * M0[0] + c6[1] * M0[1] + c6[2] * M0[2];
+  v0[1] = c6[1] * M0[0] + c6[3] * M0[1] + c6[4] * M0[2];
+  v0[2] = c6[2] * M0[0] + c6[4] * M0[1] + c6[5] * M0[2];
+  v1[0] = c6[0] * M1[0] + c6[1] * M1[1] + c6[2] * M1[2];
+  v1[1] = c6[1] * M1[0] + c6[3] * M1[1] + c6[4] * M1[2];
+  v1[2] = c6[2] * M1[0] + c6[4] * M1[1] + c6[5] * M1[2];
+  e.a = (M0[0] * v0[0] + M0[1] * v0[1] + M0[2] * v0[2]) + GSR_COV2D_DILATION;
+  e.b = M0[0] * v1[0] + M0[1] * v1[1] + M0[2] * v1[2];
+  e.c = (M1[0] * v1[0] + M1[1] * v1[1] + M1[2] * v1[2]) + GSR_COV2D_DILATION;
+}
+
+// Real SH basis of a unit direction; b[k] multiplies coefficient k
+// (Python twin: utils/sh_utils.py:74-100).
+template <int D>
+__device__ __forceinline__ void sh_basis(float x, float y, float z, float* b) {
+  b[0] = GSR_SH_C0;
+  if (D > 0) {
+    b[1] = -GSR_SH_C1 * y;
+    b[2] = GSR_SH_C1 * z;
+    b[3] = -GSR_SH_C1 * x;
+  }
+  if (D > 1) {
+    const float xx = x * x, yy = y * y, zz = z * z, xy = x * y, yz = y * z, xz = x * z;
+    b[4] = GSR_SH_C2_0 * xy;
+    b[5] = GSR_SH_C2_1 * yz;
+    b[6] = GSR_SH_C2_2 * (2.0f * zz - xx - yy);
+    b[7] = GSR_SH_C2_3 * xz;
+    b[8] = GSR_SH_C2_4 * (xx - yy);
+    if (D > 2) {
+      b[9] = GSR_SH_C3_0 * y * (3.0f * xx - yy);
+      b[10] = GSR_SH_C3_1 * xy * z;
+      b[11] = GSR_SH_C3_2 * y * (4.0f * zz - xx - yy);
+      b[12] = GSR_SH_C3_3 * z * (2.0f * zz - 3.0f * xx - 3.0f * yy);
+      b[13] = GSR_SH_C3_4 * x * (4.0f * zz - xx - yy);
+      b[14] = GSR_SH_C3_5 * z * (xx - yy);
+      b[15] = GSR_SH_C3_6 * x * (xx - 3.0f * yy);
+    }
+  }
+}
+
+// Loads the first N = (D+1)^2 coefficients x 3 channels of Gaussian i into
+// sh[3*k + c].  With the reference's (P,16,3) layout each Gaussian is 192 B,
+// 16-byte aligned: 16-byte loads.  Other M: 4-byte loads.
+template <int D>
+__device__ __forceinline__ void load_sh(const float* __restrict__ shs, int M, int i, float* sh) {
+  constexpr int N = (D + 1) * (D + 1);
+  if (M == 16) {
+    const float4* p = reinterpret_cast<const float4*>(shs) + (size_t)i * 12;
+    constexpr int Q = (3 * N + 3) / 4;
+    float4 v[Q];
+#pragma unroll
+    for (int k = 0; k < Q; k++) v[k] = p[k];
+#pragma unroll
+    for (int k = 0; k < 3 * N; k++) {
+      const float4 q = v[k / 4];
+      sh[k] = (k % 4 == 0) ? q.x : (k % 4 == 1) ? q.y : (k % 4 == 2) ? q.z : q.w;
+    }
+  } else {
+    const float* p = shs + (size_t)i * M * 3;
+#pragma unroll
+    for (int k = 0; k < 3 * N; k++) sh[k] = p[k];
+  }
+}
+
+struct FwdArgs {
+  int P, M, W, H;
+  const float* means3D; const float* scales; const float* rotations; const float* opacities;
+  const float* shs; const float* colors_precomp; const float* cov3D_precomp;
+  const float* view; const float* proj; const float* campos;
+  float scale_modifier, tanfovx, tanfovy;
+  uint32_t* records; int32_t* radii; uint32_t* tiles_touched; uint32_t* depth_keys;
+};
+
+template <int D>
+__global__ void __launch_bounds__(kBlock) preprocess_fwd_kernel(FwdArgs a) {
+  const int i = blockIdx.x * kBlock + threadIdx.x;
+  if (i >= a.P) return;
+  uint4* rec = reinterpret_cast<uint4*>(a.records) + (size_t)i * 4;
+
+  const float px3 = a.means3D[3 * i], py3 = a.means3D[3 * i + 1], pz3 = a.means3D[3 * i + 2];
+  const Vec3 pv = xform43(a.view, px3, py3, pz3);
+  bool vis = pv.z > GSR_NEAR_CULL;
+
+  int radius = 0, x0 = 0, y0 = 0, x1 = 0, y1 = 0;
+  float pxs = 0.f, pys = 0.f, conA = 0.f, conB = 0.f, conC = 0.f, hx = -1.f, hy = -1.f;
+  float opacity = 0.f;
+  if (vis) {
+    const float* PV = a.proj;
+    const float hxh = PV[0] * px3 + PV[4] * py3 + PV[8] * pz3 + PV[12];
+    const float hyh = PV[1] * px3 + PV[5] * py3 + PV[9] * pz3 + PV[13];
+    const float hwh = PV[3] * px3 + PV[7] * py3 + PV[11] * pz3 + PV[15];
+    const float pw = 1.0f / (hwh + GSR_W_EPS);
+    const float ndcx = hxh * pw, ndcy = hyh * pw;
+
+    float c6[6];
+    if (a.cov3D_precomp) {
+#pragma unroll
+      for (int k = 0; k < 6; k++) c6[k] = a.cov3D_precomp[6 * (size_t)i + k];
+    } else {
+      const float s[3] = {a.scales[3 * i], a.scales[3 * i + 1], a.scales[3 * i + 2]};
+      const float4 qv = reinterpret_cast<const float4*>(a.rotations)[i];
+      const float q[4] = {qv.x, qv.y, qv.z, qv.w};
+      cov3d_from_scale_rot(s, a.scale_modifier, q, c6);
+    }
+    Ewa e;
+    ewa_project(a.view, a.W, a.H, a.tanfovx, a.tanfovy, pv, c6, e);
+    const float det = e.a * e.c - e.b * e.b;
+    vis = det != 0.0f;
+    if (vis) {
+      const float det_inv = 1.0f / det;
+      conA = e.c * det_inv; conB = -e.b * det_inv; conC = e.a * det_inv;
+      const float mid = 0.5f * (e.a + e.c);
+      const float disc = sqrtf(fmaxf(GSR_LAMBDA_FLOOR, mid * mid - det));
+      const float lam1 = mid + disc, lam2 = mid - disc;
+      const float rf = ceilf(GSR_RADIUS_SIGMAS * sqrtf(fmaxf(lam1, lam2)));
+      radius = (rf < 2147483520.0f) ? (int)rf : 2147483647;
+      pxs = ((ndcx + 1.0f) * (float)a.W - 1.0f) * 0.5f;
+      pys = ((ndcy + 1.0f) * (float)a.H - 1.0f) * 0.5f;
+      const int gx = (a.W + GSR_TILE_X - 1) / GSR_TILE_X, gy = (a.H + GSR_TILE_Y - 1) / GSR_TILE_Y;
+      const float rr = (float)radius;
+      x0 = (int)fminf((float)gx, fmaxf(0.0f, (pxs - rr) / (float)GSR_TILE_X));
+      y0 = (int)fminf((float)gy, fmaxf(0.0f, (pys - rr) / (float)GSR_TILE_Y));
+      x1 = (int)fminf((float)gx, fmaxf(0.0f, (pxs + rr + (float)(GSR_TILE_X - 1)) / (float)GSR_TILE_X));
+      y1 = (int)fminf((float)gy, fmaxf(0.0f, (pys + rr + (float)(GSR_TILE_Y - 1)) / (float)GSR_TILE_Y));
+      vis = (x1 - x0) * (y1 - y0) > 0;
+      opacity = a.opacities[i];
+      // Half extents of the region where alpha can reach 1/255: the ellipse
+      // d^T conic d <= 2 ln(255 o) spans sqrt(2 ln(255 o) * cov_xx) in x.
+      // Widened a little so that rounding can never make it exclusive.
+      const float tau = 2.0f * __logf(255.0f * opacity);
+      if (tau > 0.0f) {
+        hx = sqrtf(tau * e.a) * 1.0005f + 0.01f;
+        hy = sqrtf(tau * e.c) * 1.0005f + 0.01f;
+      }
+    }
+  }
+  if (!vis) {
+    a.radii[i] = 0;
+    a.tiles_touched[i] = 0;
+    a.depth_keys[i] = 0xFFFFFFFFu;
+    rec[3] = make_uint4(0u, 0u, 0u, 0u);
+    return;
+  }
+
+  float r = 0.f, g = 0.f, b = 0.f;
+  unsigned clamped = 0;
+  if (a.colors_precomp) {
+    r = a.colors_precomp[3 * (size_t)i];
+    g = a.colors_precomp[3 * (size_t)i + 1];
+    b = a.colors_precomp[3 * (size_t)i + 2];
+  } else {
+    // gaussian_renderer/__init__.py:75-78
+    float dx = px3 - a.campos[0], dy = py3 - a.campos[1], dz = pz3 - a.campos[2];
+    const float len = sqrtf(dx * dx + dy * dy + dz * dz);
+    dx = dx / len; dy = dy / len; dz = dz / len;
+    constexpr int N = (D + 1) * (D + 1);
+    float bas[N], sh[3 * N], col[3];
+    sh_basis<D>(dx, dy, dz, bas);
+    load_sh<D>(a.shs, a.M, i, sh);
+#pragma unroll
+    for (int ch = 0; ch < 3; ch++) {
+      float acc = bas[0] * sh[ch];
+#pragma unroll
+      for (int k = 1; k < N; k++) acc = acc + bas[k] * sh[3 * k + ch];
+      acc = acc + GSR_SH_OFFSET;
+      if (acc < 0.0f) clamped |= 1u << ch;
+      col[ch] = fmaxf(acc, 0.0f);
+    }
+    r = col[0]; g = col[1]; b = col[2];
+  }
+
+  a.radii[i] = radius;
+  a.tiles_touched[i] = (uint32_t)((x1 - x0) * (y1 - y0));
+  a.depth_keys[i] = __float_as_uint(pv.z);
+  rec[0] = make_uint4(__float_as_uint(pxs), __float_as_uint(pys), __float_as_uint(hx), __float_as_uint(hy));
+  rec[1] = make_uint4(__float_as_uint(conA), __float_as_uint(conB), __float_as_uint(conC),
+                      __float_as_uint(opacity));
+  rec[2] = make_uint4(__float_as_uint(r), __float_as_uint(g), __float_as_uint(b), __float_as_uint(pv.z));
+  rec[3] = make_uint4((uint32_t)x0 | ((uint32_t)y0 << 16), (uint32_t)x1 | ((uint32_t)y1 << 16),
+                      (uint32_t)radius, clamped);
+}
+
+__global__ void __launch_bounds__(kBlock) mark_visible_kernel(int P, const float* __restrict__ means3D,
+                                                              const float* __restrict__ view,
+                                                              uint8_t* __restrict__ present) {
+  const int i = blockIdx.x * kBlock + threadIdx.x;
+  if (i >= P) return;
+  const Vec3 pv = xform43(view, means3D[3 * i], means3D[3 * i + 1], means3D[3 * i + 2]);
+  present[i] = pv.z > GSR_NEAR_CULL;
+}
+
+struct BwdArgs {
+  int P, M, W, H;
+  const float* means3D; const float* scales; const float* rotations; const float* shs;
+  const float* cov3D_precomp; const float* view; const float* proj; const float* campos;
+  float scale_modifier, tanfovx, tanfovy;
+  const uint32_t* records; const float* dL_dsplat;
+  float* dL_dmeans3D; float* dL_dmeans2D; float* dL_dopacities; float* dL_dshs; float* dL_dcolors;
+  float* dL_dscales; float* dL_drotations; float* dL_dcov3D;
+};
+
+// Stores n consecutive floats (n a multiple of 4, 16-byte aligned) as float4.
+template <int N>
+__device__ __forceinline__ void store_f4(float* dst, const float* v) {
+  float4* d = reinterpret_cast<float4*>(dst);
+#pragma unroll
+  for (int k = 0; k < N / 4; k++) d[k] = make_float4(v[4 * k], v[4 * k + 1], v[4 * k + 2], v[4 * k + 3]);
+}
+
+template <int D>
+__global__ void __launch_bounds__(kBlock) preprocess_bwd_kernel(BwdArgs a) {
+  const int i = blockIdx.x * kBlock + threadIdx.x;
+  if (i >= a.P) return;
+  const uint4 r3 = reinterpret_cast<const uint4*>(a.records)[(size_t)i * 4 + 3];
+  const bool vis = (int)r3.z > 0;
+  const float4* gsp = reinterpret_cast<const float4*>(a.dL_dsplat) + (size_t)i * 3;
+  float4 g0 = make_float4(0, 0, 0, 0), g1 = g0, g2 = g0;
+  if (vis) { g0 = gsp[0]; g1 = gsp[1]; g2 = gsp[2]; }
+  // g0 = (dmean2D.x, dmean2D.y, dA, dB); g1 = (dC, dopacity, dr, dg); g2 = (db, -, -, -)
+  float dmean[3] = {0.f, 0.f, 0.f};
+  float dc6[6] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+  float dscale[3] = {0.f, 0.f, 0.f}, drot[4] = {0.f, 0.f, 0.f, 0.f};
+  constexpr int N = (D + 1) * (D + 1);
+  float dsh[48];
+#pragma unroll
+  for (int k = 0; k < 48; k++) dsh[k] = 0.f;
+
+  if (vis) {
+    const float px3 = a.means3D[3 * i], py3 = a.means3D[3 * i + 1], pz3 = a.means3D[3 * i + 2];
+    const float* V = a.view;
+    const float* PV = a.proj;
+    const Vec3 pv = xform43(V, px3, py3, pz3);
+    float c6[6];
+    float s[3] = {0.f, 0.f, 0.f}, q[4] = {1.f, 0.f, 0.f, 0.f};
+    if (a.cov3D_precomp) {
+#pragma unroll
+      for (int k = 0; k < 6; k++) c6[k] = a.cov3D_precomp[6 * (size_t)i + k];
+    } else {
+      s[0] = a.scales[3 * i]; s[1] = a.scales[3 * i + 1]; s[2] = a.scales[3 * i + 2];
+      const float4 qv = reinterpret_cast<const float4*>(a.rotations)[i];
+      q[0] = qv.x; q[1] = qv.y; q[2] = qv.z; q[3] = qv.w;
+      cov3d_from_scale_rot(s, a.scale_modifier, q, c6);
+    }
+    Ewa e;
+    ewa_project(V, a.W, a.H, a.tanfovx, a.tanfovy, pv, c6, e);
+    const float fx = (float)a.W / (2.0f * a.tanfovx);
+    const float fy = (float)a.H / (2.0f * a.tanfovy);
+
+    // (a) conic -> 2D covariance -> 3D covariance and view-space mean
+    const float ca = e.a, cb = e.b, cc = e.c;
+    const float dA = g0.z, dB = g0.w, dC = g1.x;
+    const float det = ca * cc - cb * cb;
+    const float det2inv = 1.0f / (det * det + GSR_DET2_EPS);
+    float dL_da = 0.f, dL_db = 0.f, dL_dc = 0.f;
+    if (det2inv != 0.0f) {
+      dL_da = det2inv * (-cc * cc * dA + cb * cc * dB + (det - ca * cc) * dC);
+      dL_dc = det2inv * (-ca * ca * dC + ca * cb * dB + (det - ca * cc) * dA);
+      dL_db = det2inv * (2.0f * cb * cc * dA - (det + 2.0f * cb * cb) * dB + 2.0f * ca * cb * dC);
+    }
+    const float* M0 = e.M0;
+    const float* M1 = e.M1;
+    dc6[0] = M0[0] * M0[0] * dL_da + M0[0] * M1[0] * dL_db + M1[0] * M1[0] * dL_dc;
+    dc6[3] = M0[1] * M0[1] * dL_da + M0[1] * M1[1] * dL_db + M1[1] * M1[1] * dL_dc;
+    dc6[5] = M0[2] * M0[2] * dL_da + M0[2] * M1[2] * dL_db + M1[2] * M1[2] * dL_dc;
+    dc6[1] = 2.0f * M0[0] * M0[1] * dL_da + (M0[0] * M1[1] + M0[1] * M1[0]) * dL_db + 2.0f * M1[0] * M1[1] * dL_dc;
+    dc6[2] = 2.0f * M0[0] * M0[2] * dL_da + (M0[0] * M1[2] + M0[2] * M1[0]) * dL_db + 2.0f * M1[0] * M1[2] * dL_dc;
+    dc6[4] = 2.0f * M0[1] * M0[2] * dL_da + (M0[1] * M1[2] + M0[2] * M1[1]) * dL_db + 2.0f * M1[1] * M1[2] * dL_dc;
+
+    float v0[3], v1[3];
+    v0[0] = c6[0] * M0[0] + c6[1] * M0[1] + c6[2] * M0[2];
+    v0[1] = c6[1] * M0[0] + c6[3] * M0[1] + c6[4] * M0[2];
+    v0[2] = c6[2] * M0[0] + c6[4] * M0[1] + c6[5] * M0[2];
+    v1[0] = c6[0] * M1[0] + c6[1] * M1[1] + c6[2] * M1[2];
+    v1[1] = c6[1] * M1[0] + c6[3] * M1[1] + c6[4] * M1[2];
+    v1[2] = c6[2] * M1[0] + c6[4] * M1[1] + c6[5] * M1[2];
+    float dJ00 = 0.f, dJ02 = 0.f, dJ11 = 0.f, dJ12 = 0.f;
+#pragma unroll
+    for (int j = 0; j < 3; j++) {
+      const float dM0 = 2.0f * v0[j] * dL_da + v1[j] * dL_db;
+      const float dM1 = 2.0f * v1[j] * dL_dc + v0[j] * dL_db;
+      dJ00 += V[4 * j + 0] * dM0; dJ02 += V[4 * j + 2] * dM0;
+      dJ11 += V[4 * j + 1] * dM1; dJ12 += V[4 * j + 2] * dM1;
+    }
+    const float tz = 1.0f / e.tz, tz2 = tz * tz, tz3 = tz2 * tz;
+    const float dtx = e.xmul * -fx * tz2 * dJ02;
+    const float dty = e.ymul * -fy * tz2 * dJ12;
+    const float dtz = -fx * tz2 * dJ00 - fy * tz2 * dJ11 + (2.0f * fx * e.tx) * tz3 * dJ02 +
+                      (2.0f * fy * e.ty) * tz3 * dJ12;
+#pragma unroll
+    for (int j = 0; j < 3; j++) dmean[j] += V[4 * j + 0] * dtx + V[4 * j + 1] * dty + V[4 * j + 2] * dtz;
+
+    // (b) screen-space mean -> 3D mean through the perspective divide
+    const float hxh = PV[0] * px3 + PV[4] * py3 + PV[8] * pz3 + PV[12];
+    const float hyh = PV[1] * px3 + PV[5] * py3 + PV[9] * pz3 + PV[13];
+    const float hwh = PV[3] * px3 + PV[7] * py3 + PV[11] * pz3 + PV[15];
+    const float mw = 1.0f / (hwh + GSR_W_EPS);
+    const float mul1 = hxh * mw * mw, mul2 = hyh * mw * mw;
+#pragma unroll
+    for (int j = 0; j < 3; j++)
+      dmean[j] += (PV[4 * j + 0] * mw - PV[4 * j + 3] * mul1) * g0.x + (PV[4 * j + 1] * mw - PV[4 * j + 3] * mul2) * g0.y;
+
+    // (c) colour -> SH coefficients and view direction
+    if (a.shs) {
+      const float dirx = px3 - a.campos[0], diry = py3 - a.campos[1], dirz = pz3 - a.campos[2];
+      const float len = sqrtf(dirx * dirx + diry * diry + dirz * dirz);
+      const float x = dirx / len, y = diry / len, z = dirz / len;
+      float bas[N], sh[3 * N];
+      sh_basis<D>(x, y, z, bas);
+      load_sh<D>(a.shs, a.M, i, sh);
+      const float dRGB[3] = {(r3.w & 1u) ? 0.f : g1.z, (r3.w & 2u) ? 0.f : g1.w, (r3.w & 4u) ? 0.f : g2.x};
+#pragma unroll
+      for (int k = 0; k < N; k++) {
+        dsh[3 * k] = bas[k] * dRGB[0]; dsh[3 * k + 1] = bas[k] * dRGB[1]; dsh[3 * k + 2] = bas[k] * dRGB[2];
+      }
+      float ddx = 0.f, ddy = 0.f, ddz = 0.f;
+      // s_k = sh_k . dRGB; d basis_k / d(x,y,z) written out per band
+      auto sk = [&](int k) { return sh[3 * k] * dRGB[0] + sh[3 * k + 1] * dRGB[1] + sh[3 * k + 2] * dRGB[2]; };
+      if (D > 0) {
+        ddy += -GSR_SH_C1 * sk(1);
+        ddz += GSR_SH_C1 * sk(2);
+        ddx += -GSR_SH_C1 * sk(3);
+      }
+      if (D > 1) {
+        const float xx = x * x, yy = y * y, zz = z * z;
+        const float s4 = sk(4), s5 = sk(5), s6 = sk(6), s7 = sk(7), s8 = sk(8);
+        ddx += GSR_SH_C2_0 * y * s4 + GSR_SH_C2_2 * -2.0f * x * s6 + GSR_SH_C2_3 * z * s7 + GSR_SH_C2_4 * 2.0f * x * s8;
+        ddy += GSR_SH_C2_0 * x * s4 + GSR_SH_C2_1 * z * s5 + GSR_SH_C2_2 * -2.0f * y * s6 + GSR_SH_C2_4 * -2.0f * y * s8;
+        ddz += GSR_SH_C2_1 * y * s5 + GSR_SH_C2_2 * 4.0f * z * s6 + GSR_SH_C2_3 * x * s7;
+        if (D > 2) {
+          const float s9 = sk(9), s10 = sk(10), s11 = sk(11), s12 = sk(12), s13 = sk(13), s14 = sk(14), s15 = sk(15);
+          ddx += GSR_SH_C3_0 * 6.0f * x * y * s9 + GSR_SH_C3_1 * y * z * s10 + GSR_SH_C3_2 * -2.0f * x * y * s11 +
+                 GSR_SH_C3_3 * -6.0f * x * z * s12 + GSR_SH_C3_4 * (4.0f * zz - 3.0f * xx - yy) * s13 +
+                 GSR_SH_C3_5 * 2.0f * x * z * s14 + GSR_SH_C3_6 * (3.0f * xx - 3.0f * yy) * s15;
+          ddy += GSR_SH_C3_0 * (3.0f * xx - 3.0f * yy) * s9 + GSR_SH_C3_1 * x * z * s10 +
+                 GSR_SH_C3_2 * (4.0f * zz - xx - 3.0f * yy) * s11 + GSR_SH_C3_3 * -6.0f * y * z * s12 +
+                 GSR_SH_C3_4 * -2.0f * x * y * s13 + GSR_SH_C3_5 * -2.0f * y * z * s14 + GSR_SH_C3_6 * -6.0f * x * y * s15;
+          ddz += GSR_SH_C3_1 * x * y * s10 + GSR_SH_C3_2 * 8.0f * y * z * s11 +
+                 GSR_SH_C3_3 * (6.0f * zz - 3.0f * xx - 3.0f * yy) * s12 + GSR_SH_C3_4 * 8.0f * x * z * s13 +
+                 GSR_SH_C3_5 * (xx - yy) * s14;
+        }
+      }
+      const float nd = x * ddx + y * ddy + z * ddz;
+      dmean[0] += (ddx - x * nd) / len;
+      dmean[1] += (ddy - y * nd) / len;
+      dmean[2] += (ddz - z * nd) / len;
+    }
+
+    // (d) 3D covariance -> scale, rotation
+    if (!a.cov3D_precomp) {
+      float R[9];
+      quat_to_rot(q[0], q[1], q[2], q[3], R);
+      const float mod = a.scale_modifier;
+      const float S[3] = {mod * s[0], mod * s[1], mod * s[2]};
+      const float Gm[9] = {dc6[0], 0.5f * dc6[1], 0.5f * dc6[2], 0.5f * dc6[1], dc6[3],
+                           0.5f * dc6[4], 0.5f * dc6[2], 0.5f * dc6[4], dc6[5]};
+      float dR[9];
+#pragma unroll
+      for (int j = 0; j < 3; j++) {
+        float ds = 0.f;
+#pragma unroll
+        for (int r = 0; r < 3; r++) {
+          float acc = 0.f;
+#pragma unroll
+          for (int k = 0; k < 3; k++) acc += Gm[3 * r + k] * (R[3 * k + j] * S[j]);
+          const float dLm = 2.0f * acc;
+          ds += R[3 * r + j] * dLm;
+          dR[3 * r + j] = S[j] * dLm;
+        }
+        dscale[j] = mod * ds;
+      }
+      const float r = q[0], x = q[1], y = q[2], z = q[3];
+      drot[0] = 2.0f * (-z * dR[1] + y * dR[2] + z * dR[3] - x * dR[5] - y * dR[6] + x * dR[7]);
+      drot[1] = 2.0f * (y * dR[1] + z * dR[2] + y * dR[3] - 2.0f * x * dR[4] - r * dR[5] + z * dR[6] + r * dR[7] - 2.0f * x * dR[8]);
+      drot[2] = 2.0f * (-2.0f * y * dR[0] + x * dR[1] + r * dR[2] + x * dR[3] + z * dR[5] - r * dR[6] + z * dR[7] - 2.0f * y * dR[8]);
+      drot[3] = 2.0f * (-2.0f * z * dR[0] - r * dR[1] + x * dR[2] + r * dR[3] - 2.0f * z * dR[4] + y * dR[5] + x * dR[6] + y * dR[7]);
+    }
+  }
+
+  a.dL_dmeans3D[3 * (size_t)i] = dmean[0];
+  a.dL_dmeans3D[3 * (size_t)i + 1] = dmean[1];
+  a.dL_dmeans3D[3 * (size_t)i + 2] = dmean[2];
+  a.dL_dmeans2D[3 * (size_t)i] = g0.x;
+  a.dL_dmeans2D[3 * (size_t)i + 1] = g0.y;
+  a.dL_dmeans2D[3 * (size_t)i + 2] = 0.f;
+  a.dL_dopacities[i] = g1.y;
+  if (a.dL_dshs) {
+    float* dst = a.dL_dshs + (size_t)i * a.M * 3;
+    if (a.M == 16) {
+      store_f4<48>(dst, dsh);
+    } else {
+      // static indices only: a runtime-indexed dsh[] would live in scratch memory
+#pragma unroll
+      for (int k = 0; k < 48; k++)
+        if (k < a.M * 3) dst[k] = dsh[k];
+    }
+  }
+  if (a.dL_dcolors) {
+    a.dL_dcolors[3 * (size_t)i] = g1.z;
+    a.dL_dcolors[3 * (size_t)i + 1] = g1.w;
+    a.dL_dcolors[3 * (size_t)i + 2] = g2.x;
+  }
+  if (a.dL_dscales) {
+    a.dL_dscales[3 * (size_t)i] = dscale[0];
+    a.dL_dscales[3 * (size_t)i + 1] = dscale[1];
+    a.dL_dscales[3 * (size_t)i + 2] = dscale[2];
+  }
+  if (a.dL_drotations) reinterpret_cast<float4*>(a.dL_drotations)[i] = make_float4(drot[0], drot[1], drot[2], drot[3]);
+  if (a.dL_dcov3D) {
+#pragma unroll
+    for (int k = 0; k < 6; k++) a.dL_dcov3D[6 * (size_t)i + k] = dc6[k];
+  }
+}
+
+}  // namespace
+
+extern "C" int gsr_preprocess_fwd(int P, int D, int M, const float* means3D, const float* scales,
+                                  float scale_modifier, const float* rotations, const float* opacities,
+                                  const float* shs, const float* colors_precomp, const float* cov3D_precomp,
+                                  const float* viewmatrix, const float* projmatrix, const float* campos,
+                                  int W, int H, float tanfovx, float tanfovy, int prefiltered,
+                                  uint32_t* records, int32_t* radii, uint32_t* tiles_touched,
+                                  uint32_t* depth_keys, void* stream) {
+  (void)prefiltered;
+  GSR_REQUIRE(P >= 0 && W > 0 && H > 0, "preprocess_fwd: bad sizes P=%d W=%d H=%d", P, W, H);
+  if (P == 0) return GSR_OK;
+  GSR_REQUIRE(means3D && opacities && viewmatrix && projmatrix && campos, "preprocess_fwd: null input");
+  GSR_REQUIRE(records && radii && tiles_touched && depth_keys, "preprocess_fwd: null output");
+  GSR_REQUIRE((shs != nullptr) != (colors_precomp != nullptr), "preprocess_fwd: give exactly one of shs / colors_precomp");
+  GSR_REQUIRE(((scales != nullptr) && (rotations != nullptr)) != (cov3D_precomp != nullptr),
+              "preprocess_fwd: give exactly one of (scales, rotations) / cov3D_precomp");
+  GSR_REQUIRE(D >= 0 && D <= GSR_MAX_SH_DEGREE, "preprocess_fwd: SH degree %d unsupported (0..3)", D);
+  GSR_REQUIRE(!shs || M >= (D + 1) * (D + 1), "preprocess_fwd: M=%d too small for degree %d", M, D);
+  GSR_REQUIRE(W <= 16 * 65535 && H <= 16 * 65535, "preprocess_fwd: image too large");
+  FwdArgs a{P, M, W, H, means3D, scales, rotations, opacities, shs, colors_precomp, cov3D_precomp,
+            viewmatrix, projmatrix, campos, scale_modifier, tanfovx, tanfovy,
+            records, radii, tiles_touched, depth_keys};
+  hipStream_t st = (hipStream_t)stream;
+  dim3 grid(gsr::div_up(P, kBlock)), block(kBlock);
+  const int d = shs ? D : 0;
+  switch (d) {
+    case 0: hipLaunchKernelGGL(preprocess_fwd_kernel<0>, grid, block, 0, st, a); break;
+    case 1: hipLaunchKernelGGL(preprocess_fwd_kernel<1>, grid, block, 0, st, a); break;
+    case 2: hipLaunchKernelGGL(preprocess_fwd_kernel<2>, grid, block, 0, st, a); break;
+    default: hipLaunchKernelGGL(preprocess_fwd_kernel<3>, grid, block, 0, st, a); break;
+  }
+  return gsr::check_launch("preprocess_fwd");
+}
+
+extern "C" int gsr_mark_visible(int P, const float* means3D, const float* viewmatrix, uint8_t* present,
+                                void* stream) {
+  GSR_REQUIRE(P >= 0, "mark_visible: bad P");
+  if (P == 0) return GSR_OK;
+  GSR_REQUIRE(means3D && viewmatrix && present, "mark_visible: null pointer");
+  hipLaunchKernelGGL(mark_visible_kernel, dim3(gsr::div_up(P, kBlock)), dim3(kBlock), 0, (hipStream_t)stream,
+                     P, means3D, viewmatrix, present);
+  return gsr::check_launch("mark_visible");
+}
+
+extern "C" int gsr_preprocess_bwd(int P, int D, int M, const float* means3D, const float* scales,
+                                  float scale_modifier, const float* rotations, const float* shs,
+                                  const float* cov3D_precomp, const float* viewmatrix,
+                                  const float* projmatrix, const float* campos, int W, int H, float tanfovx,
+                                  float tanfovy, const uint32_t* records, const float* dL_dsplat,
+                                  float* dL_dmeans3D, float* dL_dmeans2D, float* dL_dopacities,
+                                  float* dL_dshs, float* dL_dcolors, float* dL_dscales,
+                                  float* dL_drotations, float* dL_dcov3D, void* stream) {
+  GSR_REQUIRE(P >= 0 && W > 0 && H > 0, "preprocess_bwd: bad sizes");
+  if (P == 0) return GSR_OK;
+  GSR_REQUIRE(means3D && viewmatrix && projmatrix && campos && records && dL_dsplat, "preprocess_bwd: null input");
+  GSR_REQUIRE(dL_dmeans3D && dL_dmeans2D && dL_dopacities, "preprocess_bwd: null output");
+  GSR_REQUIRE((shs != nullptr) == (dL_dshs != nullptr), "preprocess_bwd: shs and dL_dshs go together");
+  GSR_REQUIRE((shs != nullptr) != (dL_dcolors != nullptr), "preprocess_bwd: exactly one of dL_dshs / dL_dcolors");
+  GSR_REQUIRE(((scales != nullptr) && (rotations != nullptr)) != (cov3D_precomp != nullptr),
+              "preprocess_bwd: give exactly one of (scales, rotations) / cov3D_precomp");
+  GSR_REQUIRE((cov3D_precomp != nullptr) == (dL_dcov3D != nullptr), "preprocess_bwd: cov3D_precomp and dL_dcov3D go together");
+  GSR_REQUIRE((scales != nullptr) == (dL_dscales != nullptr && dL_drotations != nullptr),
+              "preprocess_bwd: scales/rotations and their gradients go together");
+  GSR_REQUIRE(D >= 0 && D <= GSR_MAX_SH_DEGREE, "preprocess_bwd: SH degree %d unsupported", D);
+  GSR_REQUIRE(!shs || (M >= (D + 1) * (D + 1) && M <= 16), "preprocess_bwd: M=%d unsupported for degree %d", M, D);
+  BwdArgs a{P, M, W, H, means3D, scales, rotations, shs, cov3D_precomp, viewmatrix, projmatrix, campos,
+            scale_modifier, tanfovx, tanfovy, records, dL_dsplat, dL_dmeans3D, dL_dmeans2D, dL_dopacities,
+            dL_dshs, dL_dcolors, dL_dscales, dL_drotations, dL_dcov3D};
+  hipStream_t st = (hipStream_t)stream;
+  dim3 grid(gsr::div_up(P, kBlock)), block(kBlock);
+  const int d = shs ? D : 0;
+  switch (d) {
+    case 0: hipLaunchKernelGGL(preprocess_bwd_kernel<0>, grid, block, 0, st, a); break;
+    case 1: hipLaunchKernelGGL(preprocess_bwd_kernel<1>, grid, block, 0, st, a); break;
+    case 2: hipLaunchKernelGGL(preprocess_bwd_kernel<2>, grid, block, 0, st, a); break;
+    default: hipLaunchKernelGGL(preprocess_bwd_kernel<3>, grid, block, 0, st, a); break;
+  }
+  return gsr::check_launch("preprocess_bwd");
+}

@@ -1,0 +1,323 @@
+"""Drop-in ``diff_gaussian_rasterization`` for AMD MI355X (gfx950).
+
+Same module name and public surface as the extension the reference imports
+(``gaussian_renderer/__init__.py:14``): ``GaussianRasterizationSettings`` with
+the 12 fields the reference constructs by keyword (``:36-49``) and
+``GaussianRasterizer`` (an ``nn.Module`` built with ``raster_settings=``,
+``:51``) whose call takes ``means3D, means2D, shs, colors_precomp, opacities,
+scales, rotations, cov3D_precomp`` and returns ``(color (3,H,W) float32,
+radii (P,) int32)`` (``:85-93``).  Gradients reach means3D, the means2D sink
+(as (x, y, 0) in NDC-scaled units, consumed by
+``scene/gaussian_model.py:405-407``), shs / colors_precomp, opacities, scales,
+rotations / cov3D_precomp.
+
+All arithmetic runs in hand-written HIP kernels inside ``libgsr_hip.so``,
+reached through the C ABI of ``include/gsr.h`` with raw device pointers.
+PyTorch only supplies device memory (caching allocator) and the current
+stream.  There is no fallback path: if the library is missing the import
+fails.
+"""
+from __future__ import annotations
+
+import ctypes as C
+import os
+from typing import NamedTuple, Optional
+
+import torch
+from torch import nn
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+_LIB_PATH = os.path.join(_HERE, "libgsr_hip.so")
+
+TILE = 16
+REC_WORDS = 16
+GRAD_WORDS = 12
+
+
+def _load():
+    if not os.path.exists(_LIB_PATH):
+        raise ImportError(
+            f"{_LIB_PATH} not found: build it with `make -C gaussian-splatting-own_amd/csrc` "
+            "(or python -c 'import __graft_entry__ as g; g.build()'); there is no non-HIP fallback")
+    lib = C.CDLL(_LIB_PATH)
+    lib.gsr_last_error.restype = C.c_char_p
+    lib.gsr_bin_prepare_bytes.restype = C.c_size_t
+    lib.gsr_bin_prepare_bytes.argtypes = [C.c_int]
+    lib.gsr_bin_emit_bytes.restype = C.c_size_t
+    lib.gsr_bin_emit_bytes.argtypes = [C.c_int, C.c_uint32, C.c_int, C.c_int]
+    vp, ci, cf = C.c_void_p, C.c_int, C.c_float
+    lib.gsr_preprocess_fwd.argtypes = [ci, ci, ci, vp, vp, cf, vp, vp, vp, vp, vp, vp, vp, vp, ci, ci, cf, cf, ci,
+                                       vp, vp, vp, vp, vp]
+    lib.gsr_mark_visible.argtypes = [ci, vp, vp, vp, vp]
+    lib.gsr_bin_prepare.argtypes = [ci, vp, vp, vp, vp, vp, C.c_size_t, vp]
+    lib.gsr_bin_emit.argtypes = [ci, C.c_uint32, ci, ci, vp, vp, vp, vp, vp, vp, vp, C.c_size_t, vp]
+    lib.gsr_blend_fwd.argtypes = [ci, ci, vp, vp, vp, vp, vp, vp, vp, vp]
+    lib.gsr_blend_bwd.argtypes = [ci, ci, vp, vp, vp, vp, vp, vp, vp, vp, vp]
+    lib.gsr_preprocess_bwd.argtypes = [ci, ci, ci, vp, vp, cf, vp, vp, vp, vp, vp, vp, ci, ci, cf, cf, vp, vp,
+                                       vp, vp, vp, vp, vp, vp, vp, vp, vp]
+    return lib
+
+
+_lib = _load()
+
+
+def _check(rc: int, what: str) -> None:
+    if rc != 0:
+        raise RuntimeError(f"libgsr_hip {what} failed ({rc}): {_lib.gsr_last_error().decode()}")
+
+
+def _ptr(t: Optional[torch.Tensor]):
+    return None if t is None else C.c_void_p(t.data_ptr())
+
+
+def _stream():
+    return C.c_void_p(torch.cuda.current_stream().cuda_stream)
+
+
+def _f32(t: Optional[torch.Tensor], name: str) -> Optional[torch.Tensor]:
+    if t is None or t.numel() == 0:
+        return None
+    if t.dtype != torch.float32:
+        raise TypeError(f"{name} must be float32, got {t.dtype}")
+    if not t.is_cuda:
+        raise ValueError(f"{name} must be on the GPU")
+    return t.contiguous()
+
+
+class GaussianRasterizationSettings(NamedTuple):
+    image_height: int
+    image_width: int
+    tanfovx: float
+    tanfovy: float
+    bg: torch.Tensor
+    scale_modifier: float
+    viewmatrix: torch.Tensor
+    projmatrix: torch.Tensor
+    sh_degree: int
+    campos: torch.Tensor
+    prefiltered: bool
+    debug: bool
+
+
+class ForwardState:
+    """Everything the forward leaves behind: op outputs, what backward needs,
+    and the intermediate buffers the parity tests inspect."""
+    __slots__ = ("P", "M", "D", "W", "H", "records", "radii", "tiles_touched", "depth_keys", "order", "offsets",
+                 "num_rendered", "point_list", "ranges", "tile_ids_sorted", "color", "final_T", "n_contrib",
+                 "view", "proj", "campos", "bg")
+
+    # views into the 64-byte records, named as the oracle names them
+    @property
+    def means2D(self):
+        return self.records.view(torch.float32)[:, 0:2]
+
+    @property
+    def conic_opacity(self):
+        return self.records.view(torch.float32)[:, 4:8]
+
+    @property
+    def rgb(self):
+        return self.records.view(torch.float32)[:, 8:11]
+
+    @property
+    def depths(self):
+        return self.records.view(torch.float32)[:, 11]
+
+    @property
+    def rects(self):
+        r = self.records[:, 12:14]
+        return torch.stack([r[:, 0] & 0xFFFF, r[:, 0] >> 16, r[:, 1] & 0xFFFF, r[:, 1] >> 16], dim=1)
+
+    @property
+    def clamped(self):
+        c = self.records[:, 15]
+        return torch.stack([c & 1, (c >> 1) & 1, (c >> 2) & 1], dim=1).to(torch.uint8)
+
+    def sort_keys(self):
+        """The 64-bit (tile << 32 | depth bits) key of every sorted instance."""
+        d = self.depth_keys.to(torch.int64)[self.point_list.to(torch.int64)]
+        return (self.tile_ids_sorted.to(torch.int64) << 32) | d
+
+
+def rasterize_forward(s: GaussianRasterizationSettings, means3D, opacities, shs=None, colors_precomp=None,
+                      scales=None, rotations=None, cov3D_precomp=None, keep_tile_ids: bool = False) -> ForwardState:
+    """preprocess -> bin -> blend on the current stream; one host read-back
+    (the instance count) in the middle, as in the module it replaces."""
+    means3D = _f32(means3D, "means3D")
+    dev = means3D.device if means3D is not None else s.bg.device
+    st = ForwardState()
+    P = 0 if means3D is None else means3D.shape[0]
+    W, H = int(s.image_width), int(s.image_height)
+    st.P, st.W, st.H, st.D = P, W, H, int(s.sh_degree)
+    opacities, shs, colors_precomp = _f32(opacities, "opacities"), _f32(shs, "shs"), _f32(colors_precomp, "colors_precomp")
+    scales, rotations, cov3D_precomp = _f32(scales, "scales"), _f32(rotations, "rotations"), _f32(cov3D_precomp, "cov3D_precomp")
+    st.M = 0 if shs is None else shs.shape[1]
+    st.view, st.proj = _f32(s.viewmatrix, "viewmatrix"), _f32(s.projmatrix, "projmatrix")
+    st.campos, st.bg = _f32(s.campos, "campos"), _f32(s.bg, "bg")
+    stream = _stream()
+    u32 = dict(dtype=torch.int32, device=dev)   # uint32 payloads carried in int32 tensors
+    st.records = torch.empty((P, REC_WORDS), **u32)
+    st.radii = torch.empty((P,), **u32)
+    st.tiles_touched = torch.empty((P,), **u32)
+    st.depth_keys = torch.empty((P,), **u32)
+    st.order = torch.empty((P,), **u32)
+    st.offsets = torch.empty((P,), **u32)
+    gx, gy = (W + TILE - 1) // TILE, (H + TILE - 1) // TILE
+    st.ranges = torch.empty((gx * gy, 2), **u32)
+    st.color = torch.empty((3, H, W), dtype=torch.float32, device=dev)
+    st.final_T = torch.empty((H, W), dtype=torch.float32, device=dev)
+    st.n_contrib = torch.empty((H, W), **u32)
+    st.tile_ids_sorted = None
+    N = 0
+    if P > 0:
+        _check(_lib.gsr_preprocess_fwd(
+            P, st.D, st.M, _ptr(means3D), _ptr(scales), float(s.scale_modifier), _ptr(rotations), _ptr(opacities),
+            _ptr(shs), _ptr(colors_precomp), _ptr(cov3D_precomp), _ptr(st.view), _ptr(st.proj), _ptr(st.campos),
+            W, H, float(s.tanfovx), float(s.tanfovy), int(bool(s.prefiltered)), _ptr(st.records), _ptr(st.radii),
+            _ptr(st.tiles_touched), _ptr(st.depth_keys), stream), "preprocess_fwd")
+        nb = _lib.gsr_bin_prepare_bytes(P)
+        scratch = torch.empty((nb,), dtype=torch.uint8, device=dev)
+        _check(_lib.gsr_bin_prepare(P, _ptr(st.depth_keys), _ptr(st.tiles_touched), _ptr(st.order), _ptr(st.offsets),
+                                    _ptr(scratch), nb, stream), "bin_prepare")
+        N = int(st.offsets[P - 1].item()) & 0xFFFFFFFF     # the pipeline's one host read-back
+    st.num_rendered = N
+    st.point_list = torch.empty((max(N, 1),), **u32)
+    if keep_tile_ids:
+        st.tile_ids_sorted = torch.empty((max(N, 1),), **u32)
+    nb = _lib.gsr_bin_emit_bytes(P, N, W, H)
+    scratch = torch.empty((nb,), dtype=torch.uint8, device=dev)
+    _check(_lib.gsr_bin_emit(P, N, W, H, _ptr(st.records), _ptr(st.order), _ptr(st.offsets), _ptr(st.point_list),
+                             _ptr(st.ranges), _ptr(st.tile_ids_sorted), _ptr(scratch), nb, stream), "bin_emit")
+    _check(_lib.gsr_blend_fwd(W, H, _ptr(st.ranges), _ptr(st.point_list), _ptr(st.records), _ptr(st.bg),
+                              _ptr(st.color), _ptr(st.final_T), _ptr(st.n_contrib), stream), "blend_fwd")
+    st.point_list = st.point_list[:N]
+    if keep_tile_ids:
+        st.tile_ids_sorted = st.tile_ids_sorted[:N]
+    return st
+
+
+def blend_backward(st: ForwardState, grad_color: torch.Tensor) -> torch.Tensor:
+    """dL/dpixels (3,H,W) -> per-Gaussian sums (P,12); see GSR_GRAD_WORDS in gsr.h."""
+    grad_color = _f32(grad_color, "grad_color")
+    dsplat = torch.zeros((st.P, GRAD_WORDS), dtype=torch.float32, device=grad_color.device)
+    if st.P > 0 and st.num_rendered > 0:
+        _check(_lib.gsr_blend_bwd(st.W, st.H, _ptr(st.ranges), _ptr(st.point_list), _ptr(st.records), _ptr(st.bg),
+                                  _ptr(st.final_T), _ptr(st.n_contrib), _ptr(grad_color), _ptr(dsplat), _stream()),
+               "blend_bwd")
+    return dsplat
+
+
+def rasterize_backward(s: GaussianRasterizationSettings, st: ForwardState, grad_color, means3D, shs=None,
+                       scales=None, rotations=None, cov3D_precomp=None, dsplat=None):
+    """Gradients of every differentiable input, as a dict."""
+    means3D = _f32(means3D, "means3D")
+    shs, scales = _f32(shs, "shs"), _f32(scales, "scales")
+    rotations, cov3D_precomp = _f32(rotations, "rotations"), _f32(cov3D_precomp, "cov3D_precomp")
+    dev = grad_color.device
+    P = st.P
+    if dsplat is None:
+        dsplat = blend_backward(st, grad_color)
+    f = dict(dtype=torch.float32, device=dev)
+    g = dict(means3D=torch.empty((P, 3), **f), means2D=torch.empty((P, 3), **f), opacities=torch.empty((P, 1), **f),
+             shs=None, colors_precomp=None, scales=None, rotations=None, cov3D_precomp=None)
+    if shs is not None:
+        g["shs"] = torch.empty((P, st.M, 3), **f)
+    else:
+        g["colors_precomp"] = torch.empty((P, 3), **f)
+    if cov3D_precomp is not None:
+        g["cov3D_precomp"] = torch.empty((P, 6), **f)
+    else:
+        g["scales"], g["rotations"] = torch.empty((P, 3), **f), torch.empty((P, 4), **f)
+    if P > 0:
+        _check(_lib.gsr_preprocess_bwd(
+            P, st.D, st.M, _ptr(means3D), _ptr(scales), float(s.scale_modifier), _ptr(rotations), _ptr(shs),
+            _ptr(cov3D_precomp), _ptr(st.view), _ptr(st.proj), _ptr(st.campos), st.W, st.H, float(s.tanfovx),
+            float(s.tanfovy), _ptr(st.records), _ptr(dsplat), _ptr(g["means3D"]), _ptr(g["means2D"]),
+            _ptr(g["opacities"]), _ptr(g["shs"]), _ptr(g["colors_precomp"]), _ptr(g["scales"]), _ptr(g["rotations"]),
+            _ptr(g["cov3D_precomp"]), _stream()), "preprocess_bwd")
+    return g
+
+
+def _empty_to_none(t):
+    return None if t is None or t.numel() == 0 else t
+
+
+class _RasterizeGaussians(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, means3D, means2D, sh, colors_precomp, opacities, scales, rotations, cov3Ds_precomp,
+                raster_settings):
+        s = raster_settings
+        args = dict(shs=_empty_to_none(sh), colors_precomp=_empty_to_none(colors_precomp),
+                    scales=_empty_to_none(scales), rotations=_empty_to_none(rotations),
+                    cov3D_precomp=_empty_to_none(cov3Ds_precomp))
+        if s.debug:
+            try:
+                st = rasterize_forward(s, means3D, opacities, **args)
+                torch.cuda.synchronize()
+            except Exception:
+                torch.save(dict(settings=tuple(s), means3D=means3D, opacities=opacities, **args), "snapshot_fw.dump")
+                print("\nAn error occured in forward. Please forward snapshot_fw.dump for debugging.")
+                raise
+        else:
+            st = rasterize_forward(s, means3D, opacities, **args)
+        ctx.raster_settings = s
+        ctx.state = st
+        ctx.save_for_backward(means3D, sh, scales, rotations, cov3Ds_precomp)
+        ctx.mark_non_differentiable(st.radii)
+        return st.color, st.radii
+
+    @staticmethod
+    def backward(ctx, grad_out_color, _grad_radii):
+        s, st = ctx.raster_settings, ctx.state
+        means3D, sh, scales, rotations, cov3Ds_precomp = ctx.saved_tensors
+        kw = dict(shs=_empty_to_none(sh), scales=_empty_to_none(scales), rotations=_empty_to_none(rotations),
+                  cov3D_precomp=_empty_to_none(cov3Ds_precomp))
+        if s.debug:
+            try:
+                g = rasterize_backward(s, st, grad_out_color, means3D, **kw)
+                torch.cuda.synchronize()
+            except Exception:
+                torch.save(dict(settings=tuple(s), means3D=means3D, grad=grad_out_color, **kw), "snapshot_bw.dump")
+                print("\nAn error occured in backward. Writing snapshot_bw.dump for debugging.\n")
+                raise
+        else:
+            g = rasterize_backward(s, st, grad_out_color, means3D, **kw)
+        return (g["means3D"], g["means2D"], g["shs"], g["colors_precomp"], g["opacities"], g["scales"],
+                g["rotations"], g["cov3D_precomp"], None)
+
+
+def rasterize_gaussians(means3D, means2D, sh, colors_precomp, opacities, scales, rotations, cov3Ds_precomp,
+                        raster_settings):
+    return _RasterizeGaussians.apply(means3D, means2D, sh, colors_precomp, opacities, scales, rotations,
+                                     cov3Ds_precomp, raster_settings)
+
+
+class GaussianRasterizer(nn.Module):
+    def __init__(self, raster_settings: GaussianRasterizationSettings):
+        super().__init__()
+        self.raster_settings = raster_settings
+
+    def markVisible(self, positions: torch.Tensor) -> torch.Tensor:
+        """Boolean mask of points in front of the near-cull plane."""
+        with torch.no_grad():
+            pos = _f32(positions, "positions")
+            P = 0 if pos is None else pos.shape[0]
+            out = torch.empty((P,), dtype=torch.uint8, device=positions.device)
+            if P:
+                view = _f32(self.raster_settings.viewmatrix, "viewmatrix")
+                _check(_lib.gsr_mark_visible(P, _ptr(pos), _ptr(view), _ptr(out), _stream()), "mark_visible")
+            return out.bool()
+
+    def forward(self, means3D, means2D, opacities, shs=None, colors_precomp=None, scales=None, rotations=None,
+                cov3D_precomp=None):
+        if (shs is None and colors_precomp is None) or (shs is not None and colors_precomp is not None):
+            raise Exception("Please provide excatly one of either SHs or precomputed colors!")
+        if ((scales is None or rotations is None) and cov3D_precomp is None) or \
+                ((scales is not None or rotations is not None) and cov3D_precomp is not None):
+            raise Exception("Please provide exactly one of either scale/rotation pair or precomputed 3D covariance!")
+        empty = torch.Tensor([])
+        return rasterize_gaussians(
+            means3D, means2D,
+            empty if shs is None else shs, empty if colors_precomp is None else colors_precomp, opacities,
+            empty if scales is None else scales, empty if rotations is None else rotations,
+            empty if cov3D_precomp is None else cov3D_precomp, self.raster_settings)

@@ -1,0 +1,172 @@
+/*
+ * gsr.h — C ABI of the MI355X (gfx950) Gaussian rasterizer library, libgsr_hip.so.
+ *
+ * This is the boundary a binding of the reference would attach to.  The
+ * reference reaches its rasterizer through the Python extension module
+ * `diff_gaussian_rasterization` (import: gaussian_renderer/__init__.py:14;
+ * settings: :36-49; module construction: :51; call: :85-93).  That module's
+ * native half is an un-vendored submodule (.gitmodules:4-6, directory empty in
+ * the reference tree), so each entry point below cites the reference CALL SITE
+ * whose work it performs rather than a native symbol of the reference.
+ *
+ * Conventions
+ *  - extern "C", plain pointers and sizes.  No torch / STL types.
+ *  - Every data pointer is a DEVICE pointer unless its name starts with h_.
+ *    The camera tensors (viewmatrix, projmatrix, campos, bg) are device
+ *    pointers too: the reference keeps them on the GPU
+ *    (scene/cameras.py:54-57, gaussian_renderer/__init__.py:22).
+ *  - The library allocates nothing.  All outputs, state and scratch are caller
+ *    memory (the Python layer hands out torch caching-allocator memory);
+ *    scratch sizes come from the *_bytes functions.  Scratch must be 256-byte
+ *    aligned.
+ *  - `stream` is a hipStream_t passed as void* (NULL = the null stream).
+ *    Calls only enqueue work; none synchronises.  The one host read-back the
+ *    pipeline needs (the number of tile instances, after gsr_bin_prepare) is
+ *    done by the caller.
+ *  - Return value: 0 = success, negative = error (GSR_E_*); gsr_last_error()
+ *    returns a message for the calling thread's last failure.
+ *  - Floating tensors are fp32, contiguous.  Layouts follow the reference's
+ *    getters (scene/gaussian_model.py:95-118): means3D (P,3); scales (P,3);
+ *    rotations (P,4) as (w,x,y,z); opacities (P,1); shs (P,M,3)
+ *    coefficient-major, channel-minor; colors_precomp (P,3); cov3D_precomp
+ *    (P,6) as (xx,xy,xz,yy,yz,zz) (utils/general_utils.py:64-73).
+ */
+#ifndef GSR_H
+#define GSR_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define GSR_VERSION 1
+
+#define GSR_OK 0
+#define GSR_E_INVALID (-1)   /* bad argument (null pointer, negative size, unsupported M/D) */
+#define GSR_E_LAUNCH (-2)    /* HIP reported an error on launch / enqueue                    */
+#define GSR_E_SCRATCH (-3)   /* scratch buffer too small or misaligned                       */
+
+/* One 64-byte record per Gaussian, written by gsr_preprocess_fwd and read by
+ * the binning and blending kernels: everything a tile needs about a splat in
+ * one aligned cache-line-sized gather.  Indices are in 4-byte words. */
+#define GSR_REC_WORDS 16
+#define GSR_REC_X 0        /* pixel-space mean x                                  */
+#define GSR_REC_Y 1        /* pixel-space mean y                                  */
+#define GSR_REC_HX 2       /* half extent in x of the alpha >= 1/255 ellipse      */
+#define GSR_REC_HY 3       /* half extent in y                                    */
+#define GSR_REC_CONIC_A 4  /* inverse 2D covariance (A, B, C) ...                 */
+#define GSR_REC_CONIC_B 5
+#define GSR_REC_CONIC_C 6
+#define GSR_REC_OPACITY 7  /* ... and opacity: the float4 "conic_opacity"          */
+#define GSR_REC_R 8        /* colour after SH evaluation / colors_precomp          */
+#define GSR_REC_G 9
+#define GSR_REC_B 10
+#define GSR_REC_DEPTH 11   /* view-space z                                        */
+#define GSR_REC_RECT_MIN 12 /* uint32: tile rect min, x | y << 16                  */
+#define GSR_REC_RECT_MAX 13 /* uint32: tile rect max (exclusive), x | y << 16      */
+#define GSR_REC_RADIUS 14   /* int32: screen radius in px, 0 = culled               */
+#define GSR_REC_CLAMPED 15  /* uint32: bit c set = colour channel c was clamped at 0 */
+
+int gsr_version(void);
+const char* gsr_last_error(void);
+
+/* ---- Stage 1: preprocess ------------------------------------------------
+ * Work of GaussianRasterizer.forward up to per-Gaussian screen-space state
+ * (reference call site gaussian_renderer/__init__.py:85-93 with the settings of
+ * :36-49): frustum cull (view z <= 0.2), projection, 3D covariance from
+ * scales/rotations (or cov3D_precomp; Python twin scene/gaussian_model.py:27-31),
+ * EWA 2D covariance, conic, radius, tile rectangle, SH -> RGB with +0.5 and
+ * clamp at 0 (or colors_precomp; Python twin utils/sh_utils.py:57-112 and
+ * gaussian_renderer/__init__.py:74-78).
+ * Exactly one of shs / colors_precomp and one of (scales, rotations) /
+ * cov3D_precomp is non-NULL.  D = active SH degree (0..3), M = coefficients
+ * stored per Gaussian and channel (>= (D+1)^2).
+ * Outputs: records (P,16) words; radii (P) int32 (0 = not visible);
+ * tiles_touched (P) uint32; depth_keys (P) uint32 = IEEE bits of view z for
+ * visible Gaussians, 0xFFFFFFFF for culled ones. */
+int gsr_preprocess_fwd(int P, int D, int M, const float* means3D, const float* scales,
+                       float scale_modifier, const float* rotations, const float* opacities,
+                       const float* shs, const float* colors_precomp, const float* cov3D_precomp,
+                       const float* viewmatrix, const float* projmatrix, const float* campos,
+                       int W, int H, float tanfovx, float tanfovy, int prefiltered,
+                       uint32_t* records, int32_t* radii, uint32_t* tiles_touched,
+                       uint32_t* depth_keys, void* stream);
+
+/* GaussianRasterizer.markVisible of the module (never called by the
+ * reference's Python): present[i] = view-space z > 0.2. */
+int gsr_mark_visible(int P, const float* means3D, const float* viewmatrix, uint8_t* present,
+                     void* stream);
+
+/* ---- Stage 2: binning ----------------------------------------------------
+ * Produces, for every 16x16 tile, the list of Gaussians whose tile rectangle
+ * covers it, ordered front to back: the result of the module's
+ * duplicateWithKeys -> 64-bit (tile | depth) radix sort -> identifyTileRanges
+ * chain, bit for bit (ties in (tile, depth) keep ascending Gaussian index).
+ * It is computed as a stable 32-bit depth sort of the P Gaussians followed by
+ * a stable sort of the tile instances by tile id, which moves ~4x fewer bytes.
+ *
+ * gsr_bin_prepare: depth-sorts the Gaussians and prefix-sums tiles_touched in
+ * that order.  order (P) uint32 = Gaussian indices front to back;
+ * offsets (P) uint32 = inclusive prefix sum; *(offsets + P - 1) is the number
+ * of tile instances N, which the caller reads back to size gsr_bin_emit. */
+size_t gsr_bin_prepare_bytes(int P);
+int gsr_bin_prepare(int P, const uint32_t* depth_keys, const uint32_t* tiles_touched,
+                    uint32_t* order, uint32_t* offsets, void* scratch, size_t scratch_bytes,
+                    void* stream);
+
+/* gsr_bin_emit: point_list (N) uint32 = Gaussian index per sorted instance;
+ * ranges (tiles,2) uint32 = [start,end) into point_list per tile, (0,0) for
+ * empty tiles.  tile_ids_sorted (N) uint32 is optional (may be NULL): the tile
+ * id of each sorted instance, from which the module's 64-bit sort keys are
+ * (tile << 32) | depth_key[point_list]. */
+size_t gsr_bin_emit_bytes(int P, uint32_t N, int W, int H);
+int gsr_bin_emit(int P, uint32_t N, int W, int H, const uint32_t* records,
+                 const uint32_t* order, const uint32_t* offsets, uint32_t* point_list,
+                 uint32_t* ranges, uint32_t* tile_ids_sorted, void* scratch,
+                 size_t scratch_bytes, void* stream);
+
+/* ---- Stage 3: blend forward ----------------------------------------------
+ * Front-to-back alpha compositing per tile (the module's per-tile render
+ * kernel): out_color (3,H,W) = sum_i c_i alpha_i T_i + T_final * bg, the
+ * image the reference receives at gaussian_renderer/__init__.py:85.
+ * final_T (H,W) fp32 and n_contrib (H,W) uint32 (1-based position in the
+ * tile list of the pixel's last contributor) are saved for backward. */
+int gsr_blend_fwd(int W, int H, const uint32_t* ranges, const uint32_t* point_list,
+                  const uint32_t* records, const float* bg, float* out_color, float* final_T,
+                  uint32_t* n_contrib, void* stream);
+
+/* ---- Stage 4: blend backward ---------------------------------------------
+ * dL_dpix (3,H,W) -> per-Gaussian sums, accumulated into dL_dsplat (P,12) fp32
+ * which the caller zero-fills first: words 0-1 dL/dmean2D in NDC-scaled units
+ * (x by W/2, y by H/2; this is what the reference reads from the .grad of its
+ * screenspace_points sink, gaussian_renderer/__init__.py:26-30,
+ * scene/gaussian_model.py:405-407), 2-4 dL/d(conic A,B,C), 5 dL/dopacity,
+ * 6-8 dL/dcolour, 9-11 unused. */
+#define GSR_GRAD_WORDS 12
+int gsr_blend_bwd(int W, int H, const uint32_t* ranges, const uint32_t* point_list,
+                  const uint32_t* records, const float* bg, const float* final_T,
+                  const uint32_t* n_contrib, const float* dL_dpix, float* dL_dsplat,
+                  void* stream);
+
+/* ---- Stage 5: preprocess backward ----------------------------------------
+ * dL_dsplat -> gradients of the op's inputs (what autograd hands back to the
+ * tensors passed at gaussian_renderer/__init__.py:85-93).  Outputs are fully
+ * written (zeros for culled Gaussians): dL_dmeans3D (P,3); dL_dmeans2D (P,3)
+ * = (x, y, 0); dL_dopacities (P,1); and, matching the inputs that were given,
+ * dL_dshs (P,M,3) or dL_dcolors (P,3), dL_dscales (P,3) + dL_drotations (P,4)
+ * or dL_dcov3D (P,6).  Pointers of the unused alternatives are NULL. */
+int gsr_preprocess_bwd(int P, int D, int M, const float* means3D, const float* scales,
+                       float scale_modifier, const float* rotations, const float* shs,
+                       const float* cov3D_precomp, const float* viewmatrix,
+                       const float* projmatrix, const float* campos, int W, int H, float tanfovx,
+                       float tanfovy, const uint32_t* records, const float* dL_dsplat,
+                       float* dL_dmeans3D, float* dL_dmeans2D, float* dL_dopacities,
+                       float* dL_dshs, float* dL_dcolors, float* dL_dscales,
+                       float* dL_drotations, float* dL_dcov3D, void* stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* GSR_H */

@@ -1,0 +1,205 @@
+"""HIP kernels (through the C ABI, via the drop-in module) against the fp32 CPU
+oracle on the same seeded inputs.
+
+Bars: per-Gaussian preprocess outputs, sort keys / values and tile ranges are
+BIT-EXACT; images within 1e-5 absolute per pixel, except pixels the oracle
+flags as sitting on a discontinuous threshold (alpha = 1/255, T = 1e-4,
+power = 0) within fp32 rounding, whose share is bounded; gradients within a
+relative tolerance (their sums run in a different order on the GPU).
+"""
+import math
+
+import numpy as np
+import pytest
+import torch
+
+from scenes import cloud_numpy, make_scene, oracle_settings
+
+pytestmark = pytest.mark.gpu
+
+PIX_TOL = 1e-5          # north-star tolerance: 1e-5 fp32 per pixel
+MARGIN_SAFE = 4.0       # oracle margin below which a threshold decision may flip in fp32
+
+
+def _gpu_settings(cam, bg, deg, mod, debug=False):
+    import diff_gaussian_rasterization as dgr
+    dev = "cuda"
+    return dgr.GaussianRasterizationSettings(
+        image_height=cam.image_height, image_width=cam.image_width,
+        tanfovx=math.tan(cam.FoVx * 0.5), tanfovy=math.tan(cam.FoVy * 0.5), bg=bg.to(dev),
+        scale_modifier=mod, viewmatrix=cam.world_view_transform.to(dev), projmatrix=cam.full_proj_transform.to(dev),
+        sh_degree=deg, campos=cam.camera_center.to(dev), prefiltered=False, debug=debug)
+
+
+def _bits(x):
+    return np.ascontiguousarray(x, dtype=np.float32).view(np.uint32)
+
+
+CASES = {
+    # name: (P, W, H, degree, coeffs, bg, scale_modifier, kwargs)
+    "c1_10k_256_deg0": (10_000, 256, 256, 0, 1, (0.0, 0.0, 0.0), 1.0, {}),
+    "ragged_5k_333x200_deg3": (5_000, 333, 200, 3, 16, (0.2, 0.4, 0.9), 0.8, {}),
+    "deg2_of_16": (8_000, 400, 240, 2, 16, (1.0, 1.0, 1.0), 1.0, {}),
+    "deg1_close_camera": (6_000, 320, 320, 1, 16, (0.0, 0.0, 0.0), 1.0, dict(distance=1.6, scale_mult=2.0)),
+    "skewed_hot_tiles": (30_000, 320, 192, 3, 16, (0.1, 0.1, 0.1), 1.0, dict(skew_fraction=0.5)),
+    "low_opacity_no_termination": (8_000, 256, 256, 3, 16, (0.0, 0.0, 0.0), 1.0, dict(opacity_const=0.1)),
+}
+
+
+def _run_case(oracle32, name):
+    import diff_gaussian_rasterization as dgr
+    P, W, H, deg, coeffs, bgc, mod, kw = CASES[name]
+    cloud, cam, bg, _ = make_scene(P, W, H, sh_degree=deg, seed=11, bg=bgc, coeffs=coeffs, **kw)
+    s_cpu = oracle_settings(cam, bg, deg, mod)
+    cn = cloud_numpy(cloud)
+    ref = oracle32.forward(s_cpu, **cn)
+    s_gpu = _gpu_settings(cam, bg, deg, mod)
+    c = cloud.to("cuda")
+    st = dgr.rasterize_forward(s_gpu, c.xyz, c.opacity, shs=c.features, scales=c.scaling, rotations=c.rotation,
+                               keep_tile_ids=True)
+    torch.cuda.synchronize()
+    return cloud, cam, bg, mod, s_cpu, s_gpu, cn, ref, st
+
+
+@pytest.mark.parametrize("name", list(CASES))
+def test_forward_stages(oracle32, name):
+    cloud, cam, bg, mod, s_cpu, s_gpu, cn, ref, st = _run_case(oracle32, name)
+    pre, bn, fw = ref["pre"], ref["bin"], ref["fwd"]
+    print(name, "P", st.P, "visible", int((pre["radii"] > 0).sum()), "instances", bn["n_dup"], flush=True)
+    assert bn["n_dup"] > 0
+
+    # --- preprocess: bit-exact ---------------------------------------------------
+    radii = st.radii.cpu().numpy()
+    assert np.array_equal(radii, pre["radii"])
+    vis = radii > 0
+    assert np.array_equal(st.tiles_touched.cpu().numpy().view(np.uint32), pre["tiles_touched"])
+    assert np.array_equal(st.rects.cpu().numpy()[vis], pre["rects"][vis])
+    assert np.array_equal(_bits(st.means2D.cpu().numpy())[vis], _bits(pre["means2D"])[vis])
+    assert np.array_equal(_bits(st.depths.cpu().numpy())[vis], _bits(pre["depths"])[vis])
+    assert np.array_equal(_bits(st.conic_opacity.cpu().numpy())[vis], _bits(pre["conic_opacity"])[vis])
+    assert np.array_equal(_bits(st.rgb.cpu().numpy())[vis], _bits(pre["rgb"])[vis])
+    assert np.array_equal(st.clamped.cpu().numpy()[vis], pre["clamped"][vis])
+
+    # --- binning: bit-exact keys, values, ranges ------------------------------------
+    assert st.num_rendered == bn["n_dup"]
+    assert np.array_equal(st.point_list.cpu().numpy().view(np.uint32), bn["point_list"])
+    assert np.array_equal(st.sort_keys().cpu().numpy().view(np.uint64), bn["keys"])
+    assert np.array_equal(st.ranges.cpu().numpy().view(np.uint32), bn["ranges"])
+
+    # --- blend: 1e-5 per pixel away from threshold coin-flips --------------------------
+    color = st.color.cpu().numpy()
+    safe = fw["margin"] >= MARGIN_SAFE
+    frac_unsafe = 1.0 - safe.mean()
+    print(name, "threshold-borderline pixels: %.4f%%" % (100 * frac_unsafe), flush=True)
+    assert frac_unsafe < 5e-3
+    diff = np.abs(color - fw["color"])
+    assert diff[:, safe].max() <= PIX_TOL, diff[:, safe].max()
+    assert diff.max() < 2e-2                       # a flipped decision moves a pixel by one contribution at most
+    assert np.array_equal(st.n_contrib.cpu().numpy().view(np.uint32)[safe], fw["n_contrib"][safe])
+    np.testing.assert_allclose(st.final_T.cpu().numpy()[safe], fw["final_T"][safe], rtol=2e-5, atol=1e-7)
+
+
+def _rel_err(got, ref):
+    scale = np.abs(ref).max() + 1e-20
+    return np.abs(got - ref).max() / scale
+
+
+@pytest.mark.parametrize("name", ["c1_10k_256_deg0", "ragged_5k_333x200_deg3", "deg1_close_camera",
+                                  "skewed_hot_tiles", "low_opacity_no_termination"])
+def test_backward(oracle32, name):
+    import diff_gaussian_rasterization as dgr
+    cloud, cam, bg, mod, s_cpu, s_gpu, cn, ref, st = _run_case(oracle32, name)
+    rng = np.random.default_rng(3)
+    dL = rng.standard_normal((3, cam.image_height, cam.image_width)).astype(np.float32)
+    # backward of the oracle FROM THE GPU's forward state where the two may legitimately differ
+    # (n_contrib / final_T of borderline pixels), so that only the backward kernels are compared
+    fw = dict(ref["fwd"])
+    fw["final_T"] = st.final_T.cpu().numpy()
+    fw["n_contrib"] = st.n_contrib.cpu().numpy().view(np.uint32)
+    state = dict(pre=ref["pre"], bin=ref["bin"], fwd=fw)
+    g_ref = oracle32.backward(s_cpu, state, dL, cn["means3D"], scales=cn["scales"], rotations=cn["rotations"],
+                              shs=cn["shs"])
+    c = cloud.to("cuda")
+    dLg = torch.from_numpy(dL).cuda()
+    dsplat = dgr.blend_backward(st, dLg)
+    g = dgr.rasterize_backward(s_gpu, st, dLg, c.xyz, shs=c.features, scales=c.scaling, rotations=c.rotation,
+                               dsplat=dsplat)
+    torch.cuda.synchronize()
+    ds = dsplat.cpu().numpy()
+    bb = g_ref["blend"]
+    for nm, got, want in [("mean2D", ds[:, 0:2], bb["dL_dmean2D"]), ("conic", ds[:, 2:5], bb["dL_dconic"]),
+                          ("opacity", ds[:, 5], bb["dL_dopacity"]), ("color", ds[:, 6:9], bb["dL_dcolor"])]:
+        e = _rel_err(got, want)
+        print(name, "blend_bwd", nm, "rel err %.2e" % e, flush=True)
+        assert e < 2e-4, (nm, e)
+    for nm in ("means3D", "means2D", "shs", "opacities", "scales", "rotations"):
+        got, want = g[nm].cpu().numpy(), g_ref[nm]
+        e = _rel_err(got, want.reshape(got.shape))
+        print(name, "grad", nm, "rel err %.2e" % e, flush=True)
+        assert e < 3e-4, (nm, e)
+        assert np.isfinite(got).all()
+
+
+def test_module_api_and_alternative_inputs(oracle32):
+    """The nn.Module surface, autograd wiring, and the two interchangeable input
+    paths of the reference (gaussian_renderer/__init__.py:62-66 and :72-80)."""
+    import diff_gaussian_rasterization as dgr
+    from oracle import torch_ref
+    cloud, cam, bg, _ = make_scene(4_000, 200, 120, sh_degree=3, seed=5, bg=(0.3, 0.3, 0.3))
+    s = _gpu_settings(cam, bg, 3, 1.0)
+    c = cloud.to("cuda")
+    leaf = lambda t: t.clone().requires_grad_(True)
+    m3, op, sc, ro, sh = leaf(c.xyz), leaf(c.opacity), leaf(c.scaling), leaf(c.rotation), leaf(c.features)
+    sink = torch.zeros_like(m3, requires_grad=True)
+    rast = dgr.GaussianRasterizer(raster_settings=s)
+    img, radii = rast(means3D=m3, means2D=sink, shs=sh, colors_precomp=None, opacities=op, scales=sc, rotations=ro,
+                      cov3D_precomp=None)
+    assert img.shape == (3, 120, 200) and img.dtype == torch.float32
+    assert radii.shape == (4000,) and radii.dtype == torch.int32
+    w = torch.randn_like(img)
+    (img * w).sum().backward()
+    for t in (m3, op, sc, ro, sh, sink):
+        assert t.grad is not None and torch.isfinite(t.grad).all()
+    assert sink.grad.shape == (4000, 3) and float(sink.grad[:, 2].abs().max()) == 0.0
+    vis = radii > 0
+    assert float(sink.grad[~vis].abs().max()) == 0.0 and float(sink.grad[vis].abs().max()) > 0.0
+    assert torch.equal(rast.markVisible(c.xyz).cpu(), torch.from_numpy(
+        oracle32.mark_visible(oracle_settings(cam, bg, 3, 1.0), cloud.xyz.numpy())))
+
+    # SH evaluated in Python and handed over as colors_precomp; covariance precomputed in Python
+    with torch.no_grad():
+        d = c.xyz - s.campos[None]
+        d = d / d.norm(dim=1, keepdim=True)
+        col = torch.clamp_min(torch_ref.sh_to_rgb(3, c.features, d) + 0.5, 0.0)
+        cov = torch_ref.cov3d(c.scaling, 1.0, c.rotation)
+    col, cov = leaf(col), leaf(cov)
+    m3b, opb = leaf(c.xyz), leaf(c.opacity)
+    img2, radii2 = rast(means3D=m3b, means2D=torch.zeros_like(m3b, requires_grad=True), shs=None, colors_precomp=col,
+                        opacities=opb, scales=None, rotations=None, cov3D_precomp=cov)
+    (img2 * w).sum().backward()
+    assert float((img2 - img).abs().max()) < 2e-2 and float((img2 - img).abs().mean()) < 1e-5
+    assert (radii2 != radii).float().mean() < 1e-3
+    assert _rel_err(opb.grad.cpu().numpy(), op.grad.cpu().numpy()) < 1e-2
+    assert col.grad.shape == (4000, 3) and cov.grad.shape == (4000, 6)
+
+    with pytest.raises(Exception):
+        rast(means3D=m3, means2D=sink, shs=sh, colors_precomp=col, opacities=op, scales=sc, rotations=ro)
+    with pytest.raises(Exception):
+        rast(means3D=m3, means2D=sink, shs=sh, opacities=op, scales=sc, rotations=ro, cov3D_precomp=cov)
+
+
+def test_empty_and_fully_culled():
+    import diff_gaussian_rasterization as dgr
+    cloud, cam, bg, _ = make_scene(64, 64, 48, sh_degree=0, seed=1, bg=(0.5, 0.25, 0.125), coeffs=1)
+    s = _gpu_settings(cam, bg, 0, 1.0)
+    c = cloud.to("cuda")
+    behind = c.xyz.clone()
+    behind[:, 2] += 100.0          # all behind the camera
+    st = dgr.rasterize_forward(s, behind, c.opacity, shs=c.features, scales=c.scaling, rotations=c.rotation)
+    torch.cuda.synchronize()
+    assert st.num_rendered == 0 and int(st.radii.abs().sum()) == 0
+    want = bg.cuda()[:, None, None].expand(3, 48, 64)
+    assert torch.equal(st.color, want)
+    g = dgr.rasterize_backward(s, st, torch.ones_like(st.color), behind, shs=c.features, scales=c.scaling,
+                               rotations=c.rotation)
+    assert all(float(v.abs().max()) == 0.0 for v in g.values() if v is not None)
