@@ -1,0 +1,222 @@
+#!/usr/bin/env python3
+"""Benchmark of the MI355X Gaussian rasterizer on the reference's training step.
+
+    python bench.py [--gpus N] [--steps K] [--warmup W] [--workload c3]
+
+One "step" is the reference's own timed span of a training iteration
+(train.py:67-95): model activations -> render() -> 0.8*L1 + 0.2*(1-SSIM) ->
+backward.  The optimiser step is outside that span in the reference
+(train.py:126-128) and outside it here.  The default workload is BASELINE.json
+config 3: 1M synthetic Gaussians, 1920x1080, SH degree 3 (see
+gsplat_host/synthetic.py for the seeded recipe).  With --gpus N (launched by
+torch.distributed.run, one rank per GPU) every rank renders its own view of the
+same replicated cloud (camera rotated by rank*45 degrees) and the scalar loss is
+all-reduced over RCCL: per-GPU work is fixed, scaling is weak.
+
+Rank 0 prints ONE JSON line.  `value` is render throughput, Msplats/s = Gaussians
+submitted per second of forward render (preprocess + binning + blend), summed
+over ranks, measured with device events inside the timed training steps;
+`ms_per_step` is the whole train step.  `roofline` prices the dominant
+hand-written kernel against HBM with the ALGORITHMIC bytes of one launch;
+`cpu_baseline` times the C oracle's forward render of the same workload on the
+host cores (rank 0, N=1 only).
+"""
+from __future__ import annotations
+
+import argparse
+import json
+import math
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, os.path.join(ROOT, "gaussian-splatting-own_amd"))
+sys.path.insert(0, ROOT)
+
+import torch  # noqa: E402
+import torch.distributed as dist  # noqa: E402
+
+HBM_PEAK_GBS = 8000.0     # MI355X HBM3E spec peak
+
+WORKLOADS = {
+    # name: (P, W, H, sh_degree, skew_fraction)   -- BASELINE.json configs
+    "c1": (10_000, 256, 256, 0, 0.0),
+    "c2": (100_000, 800, 800, 3, 0.0),
+    "c3": (1_000_000, 1920, 1080, 3, 0.0),
+    "c5": (6_000_000, 1920, 1080, 3, 0.5),
+}
+
+
+def algorithmic_bytes(P, N, W, H, M=16):
+    """Per-launch algorithmic HBM bytes of each stage (minimum traffic with
+    perfect on-chip reuse): B_in = 44 + 12*M bytes of attributes per Gaussian,
+    ~80 B of per-Gaussian state out; one 40-byte splat (id 4, xy 8, conic+opacity
+    16, rgb 12) per (tile, splat) instance; 20 B per pixel out of the forward
+    blend, 32 B per pixel into the backward blend plus 36 B of gradient per
+    Gaussian."""
+    b_in = 44 + 12 * M
+    return {
+        "preprocess_fwd": P * (b_in + 80),
+        "blend_fwd": 40 * N + 20 * W * H,
+        "blend_bwd": 40 * N + 32 * W * H + 36 * P,
+        "preprocess_bwd": P * (b_in + 80 + 36 + b_in + 12),
+    }
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=20)
+    ap.add_argument("--warmup", type=int, default=5)
+    ap.add_argument("--workload", default="c3", choices=sorted(WORKLOADS))
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    args = ap.parse_args()
+
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if world > 1:
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group("nccl", rank=rank, world_size=world)
+    if args.gpus != world and rank == 0 and world > 1:
+        print(f"warning: --gpus {args.gpus} but WORLD_SIZE {world}", file=sys.stderr)
+    torch.cuda.set_device(local_rank)
+    dev = torch.device("cuda", local_rank)
+
+    import diff_gaussian_rasterization as dgr
+    from gsplat_host.cameras import orbit_camera
+    from gsplat_host.loss import photometric_loss
+    from gsplat_host.model import GaussianParams
+    from gsplat_host.render import PipelineParams, render
+    from gsplat_host.synthetic import make_cloud
+
+    P, W, H, deg, skew = WORKLOADS[args.workload]
+    cloud = make_cloud(P, sh_degree=deg, seed=0, skew_fraction=skew)
+    model = GaussianParams(cloud, max_sh_degree=3 if deg == 3 else deg, device=dev)
+    cam = orbit_camera(W, H, angle_deg=45.0 * rank, device=dev)
+    bg = torch.zeros(3, device=dev)                                   # train.py:41
+    gt = torch.rand(3, H, W, generator=torch.Generator().manual_seed(1)).to(dev)
+    pipe = PipelineParams()
+    params = [p for p in model.parameters()]
+
+    timer = dgr.StageTimer()
+    fwd_events = []
+
+    def step(timed: bool):
+        for p in params:
+            p.grad = None
+        if timed:
+            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            e0.record()
+        out = render(cam, model, pipe, bg)
+        if timed:
+            e1.record()
+            fwd_events.append((e0, e1))
+        loss = photometric_loss(out["render"], gt)
+        loss.backward()
+        if world > 1:
+            lv = loss.detach().clone()
+            dist.all_reduce(lv)                                       # RCCL over xGMI: one fp32 scalar
+            lv /= world
+        return out
+
+    def barrier():
+        torch.cuda.synchronize()
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    for _ in range(args.warmup):
+        step(False)
+    barrier()
+    dgr.set_stage_timer(timer)
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        out = step(True)
+    barrier()
+    elapsed = time.perf_counter() - t0
+    dgr.set_stage_timer(None)
+
+    if world > 1:
+        t = torch.tensor([elapsed], device=dev, dtype=torch.float64)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        elapsed = float(t.item())
+    render_ms = sum(a.elapsed_time(b) for a, b in fwd_events) / len(fwd_events)
+    if world > 1:
+        t = torch.tensor([render_ms], device=dev, dtype=torch.float64)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        render_ms = float(t.item())
+    ms_per_step = 1e3 * elapsed / args.steps
+    msplats = world * P / (render_ms * 1e-3) / 1e6
+
+    if rank == 0:
+        stage_ms = timer.mean_ms()
+        N = int((out["radii"] > 0).sum().item())
+        st_N = _instances(dgr, cam, model, bg)
+        alg = algorithmic_bytes(P, st_N, W, H)
+        dominant = max(alg, key=lambda k: stage_ms.get(k, 0.0))
+        achieved = alg[dominant] / (stage_ms[dominant] * 1e-3) / 1e9
+        kernels = {k: {"ms": round(stage_ms[k], 4), "algorithmic_GB": round(alg[k] / 1e9, 4) if k in alg else None,
+                       "GBps": round(alg[k] / (stage_ms[k] * 1e-3) / 1e9, 1) if k in alg else None}
+                   for k in stage_ms}
+        line = {
+            "metric": "train-step ms + render Msplats/s @1080p, 1M Gaussians, 1/2/4/8 MI355X",
+            "value": round(msplats, 2), "unit": "Msplats/s", "n_gpus": world, "steps": args.steps,
+            "warmup": args.warmup, "ms_per_step": round(ms_per_step, 3), "higher_is_better": True,
+            "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+            "config": {"workload": f"{args.workload}: {P} Gaussians, {W}x{H}, SH degree {deg}, full train step "
+                                   "(activations + render + 0.8*L1+0.2*(1-SSIM) + backward), one view per GPU",
+                       "gaussians": P, "visible": N, "tile_instances": st_N, "views_per_step": world},
+            "train_step_ms": round(ms_per_step, 3), "render_ms": round(render_ms, 3),
+            "roofline": {"bound": "hbm", "kernel": dominant, "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS,
+                         "unit": "GB/s", "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": None},
+            "kernels": kernels,
+        }
+        if world == 1 and not args.no_cpu_baseline:
+            line["cpu_baseline"] = cpu_baseline(cloud, W, H, deg)
+        print(json.dumps(line), flush=True)
+    if world > 1:
+        dist.barrier()
+        dist.destroy_process_group()
+
+
+def _instances(dgr, cam, model, bg):
+    """Number of (tile, splat) instances of the benchmarked view (untimed)."""
+    with torch.no_grad():
+        s = dgr.GaussianRasterizationSettings(
+            image_height=cam.image_height, image_width=cam.image_width, tanfovx=math.tan(cam.FoVx * 0.5),
+            tanfovy=math.tan(cam.FoVy * 0.5), bg=bg, scale_modifier=1.0, viewmatrix=cam.world_view_transform,
+            projmatrix=cam.full_proj_transform, sh_degree=model.active_sh_degree, campos=cam.camera_center,
+            prefiltered=False, debug=False)
+        st = dgr.rasterize_forward(s, model.get_xyz, model.get_opacity, shs=model.get_features,
+                                   scales=model.get_scaling, rotations=model.get_rotation)
+        return st.num_rendered
+
+
+def cpu_baseline(cloud, W, H, deg):
+    """Forward render of the same workload by the C oracle (a port: the
+    reference has no CPU rasterizer), on the host cores, timed once."""
+    import numpy as np
+    import oracle
+    from gsplat_host.cameras import orbit_camera
+    threads = int(os.environ.get("OMP_NUM_THREADS", "0")) or min(os.cpu_count() or 1, 16)
+    os.environ["OMP_NUM_THREADS"] = str(threads)
+    oracle.build()
+    o = oracle.Oracle(np.float32)
+    cam = orbit_camera(W, H)
+    s = oracle.Settings(H, W, math.tan(cam.FoVx / 2), math.tan(cam.FoVy / 2), np.zeros(3, np.float32), 1.0,
+                        cam.world_view_transform.numpy(), cam.full_proj_transform.numpy(), deg,
+                        cam.camera_center.numpy())
+    arrs = dict(means3D=cloud.xyz.numpy(), opacities=cloud.opacity.numpy(), scales=cloud.scaling.numpy(),
+                rotations=cloud.rotation.numpy(), shs=cloud.features.numpy())
+    t0 = time.perf_counter()
+    o.forward(s, want_margin=False, **arrs)
+    dt = time.perf_counter() - t0
+    return {"value": round(cloud.count / dt / 1e6, 4), "unit": "Msplats/s", "cores": threads, "kind": "port",
+            "sample": f"1 forward render (preprocess + binning + blend) of the full workload, {dt:.2f} s; "
+                      "blend and preprocess run on all cores (OpenMP), the sort on one"}
+
+
+if __name__ == "__main__":
+    main()

@@ -61,7 +61,44 @@ def _load():
 _lib = _load()
 
 
-def _check(rc: int, what: str) -> None:
+class StageTimer:
+    """Optional per-stage device timing: while one is installed with
+    ``set_stage_timer``, every C-ABI call is bracketed by a pair of events on
+    the current stream (the stream the kernels run on)."""
+
+    def __init__(self):
+        self.events = {}
+
+    def bracket(self, name):
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        self.events.setdefault(name, []).append((e0, e1))
+        return e0, e1
+
+    def mean_ms(self):
+        """Synchronises, then {stage: mean milliseconds per call}."""
+        torch.cuda.synchronize()
+        return {k: sum(a.elapsed_time(b) for a, b in v) / len(v) for k, v in self.events.items()}
+
+    def calls(self):
+        return {k: len(v) for k, v in self.events.items()}
+
+
+_timer: Optional[StageTimer] = None
+
+
+def set_stage_timer(timer: Optional[StageTimer]) -> None:
+    global _timer
+    _timer = timer
+
+
+def _run(what: str, fn, *args) -> None:
+    if _timer is not None:
+        e0, e1 = _timer.bracket(what)
+        e0.record()
+        rc = fn(*args)
+        e1.record()
+    else:
+        rc = fn(*args)
     if rc != 0:
         raise RuntimeError(f"libgsr_hip {what} failed ({rc}): {_lib.gsr_last_error().decode()}")
 
@@ -170,15 +207,14 @@ def rasterize_forward(s: GaussianRasterizationSettings, means3D, opacities, shs=
     st.tile_ids_sorted = None
     N = 0
     if P > 0:
-        _check(_lib.gsr_preprocess_fwd(
-            P, st.D, st.M, _ptr(means3D), _ptr(scales), float(s.scale_modifier), _ptr(rotations), _ptr(opacities),
+        _run("preprocess_fwd", _lib.gsr_preprocess_fwd, P, st.D, st.M, _ptr(means3D), _ptr(scales), float(s.scale_modifier), _ptr(rotations), _ptr(opacities),
             _ptr(shs), _ptr(colors_precomp), _ptr(cov3D_precomp), _ptr(st.view), _ptr(st.proj), _ptr(st.campos),
             W, H, float(s.tanfovx), float(s.tanfovy), int(bool(s.prefiltered)), _ptr(st.records), _ptr(st.radii),
-            _ptr(st.tiles_touched), _ptr(st.depth_keys), stream), "preprocess_fwd")
+            _ptr(st.tiles_touched), _ptr(st.depth_keys), stream)
         nb = _lib.gsr_bin_prepare_bytes(P)
         scratch = torch.empty((nb,), dtype=torch.uint8, device=dev)
-        _check(_lib.gsr_bin_prepare(P, _ptr(st.depth_keys), _ptr(st.tiles_touched), _ptr(st.order), _ptr(st.offsets),
-                                    _ptr(scratch), nb, stream), "bin_prepare")
+        _run("bin_prepare", _lib.gsr_bin_prepare, P, _ptr(st.depth_keys), _ptr(st.tiles_touched), _ptr(st.order), _ptr(st.offsets),
+                                    _ptr(scratch), nb, stream)
         N = int(st.offsets[P - 1].item()) & 0xFFFFFFFF     # the pipeline's one host read-back
     st.num_rendered = N
     st.point_list = torch.empty((max(N, 1),), **u32)
@@ -186,10 +222,10 @@ def rasterize_forward(s: GaussianRasterizationSettings, means3D, opacities, shs=
         st.tile_ids_sorted = torch.empty((max(N, 1),), **u32)
     nb = _lib.gsr_bin_emit_bytes(P, N, W, H)
     scratch = torch.empty((nb,), dtype=torch.uint8, device=dev)
-    _check(_lib.gsr_bin_emit(P, N, W, H, _ptr(st.records), _ptr(st.order), _ptr(st.offsets), _ptr(st.point_list),
-                             _ptr(st.ranges), _ptr(st.tile_ids_sorted), _ptr(scratch), nb, stream), "bin_emit")
-    _check(_lib.gsr_blend_fwd(W, H, _ptr(st.ranges), _ptr(st.point_list), _ptr(st.records), _ptr(st.bg),
-                              _ptr(st.color), _ptr(st.final_T), _ptr(st.n_contrib), stream), "blend_fwd")
+    _run("bin_emit", _lib.gsr_bin_emit, P, N, W, H, _ptr(st.records), _ptr(st.order), _ptr(st.offsets), _ptr(st.point_list),
+                             _ptr(st.ranges), _ptr(st.tile_ids_sorted), _ptr(scratch), nb, stream)
+    _run("blend_fwd", _lib.gsr_blend_fwd, W, H, _ptr(st.ranges), _ptr(st.point_list), _ptr(st.records), _ptr(st.bg),
+                              _ptr(st.color), _ptr(st.final_T), _ptr(st.n_contrib), stream)
     st.point_list = st.point_list[:N]
     if keep_tile_ids:
         st.tile_ids_sorted = st.tile_ids_sorted[:N]
@@ -201,9 +237,8 @@ def blend_backward(st: ForwardState, grad_color: torch.Tensor) -> torch.Tensor:
     grad_color = _f32(grad_color, "grad_color")
     dsplat = torch.zeros((st.P, GRAD_WORDS), dtype=torch.float32, device=grad_color.device)
     if st.P > 0 and st.num_rendered > 0:
-        _check(_lib.gsr_blend_bwd(st.W, st.H, _ptr(st.ranges), _ptr(st.point_list), _ptr(st.records), _ptr(st.bg),
-                                  _ptr(st.final_T), _ptr(st.n_contrib), _ptr(grad_color), _ptr(dsplat), _stream()),
-               "blend_bwd")
+        _run("blend_bwd", _lib.gsr_blend_bwd, st.W, st.H, _ptr(st.ranges), _ptr(st.point_list), _ptr(st.records), _ptr(st.bg),
+                                  _ptr(st.final_T), _ptr(st.n_contrib), _ptr(grad_color), _ptr(dsplat), _stream())
     return dsplat
 
 
@@ -229,12 +264,11 @@ def rasterize_backward(s: GaussianRasterizationSettings, st: ForwardState, grad_
     else:
         g["scales"], g["rotations"] = torch.empty((P, 3), **f), torch.empty((P, 4), **f)
     if P > 0:
-        _check(_lib.gsr_preprocess_bwd(
-            P, st.D, st.M, _ptr(means3D), _ptr(scales), float(s.scale_modifier), _ptr(rotations), _ptr(shs),
+        _run("preprocess_bwd", _lib.gsr_preprocess_bwd, P, st.D, st.M, _ptr(means3D), _ptr(scales), float(s.scale_modifier), _ptr(rotations), _ptr(shs),
             _ptr(cov3D_precomp), _ptr(st.view), _ptr(st.proj), _ptr(st.campos), st.W, st.H, float(s.tanfovx),
             float(s.tanfovy), _ptr(st.records), _ptr(dsplat), _ptr(g["means3D"]), _ptr(g["means2D"]),
             _ptr(g["opacities"]), _ptr(g["shs"]), _ptr(g["colors_precomp"]), _ptr(g["scales"]), _ptr(g["rotations"]),
-            _ptr(g["cov3D_precomp"]), _stream()), "preprocess_bwd")
+            _ptr(g["cov3D_precomp"]), _stream())
     return g
 
 
@@ -305,7 +339,7 @@ class GaussianRasterizer(nn.Module):
             out = torch.empty((P,), dtype=torch.uint8, device=positions.device)
             if P:
                 view = _f32(self.raster_settings.viewmatrix, "viewmatrix")
-                _check(_lib.gsr_mark_visible(P, _ptr(pos), _ptr(view), _ptr(out), _stream()), "mark_visible")
+                _run("mark_visible", _lib.gsr_mark_visible, P, _ptr(pos), _ptr(view), _ptr(out), _stream())
             return out.bool()
 
     def forward(self, means3D, means2D, opacities, shs=None, colors_precomp=None, scales=None, rotations=None,

@@ -1,0 +1,93 @@
+"""The N>1 path on CPU: two processes over gloo shard four views, render their
+share (with the CPU oracle standing in for the GPU kernels), all-reduce the
+scalar loss, and must agree with a single process doing all four views."""
+import math
+import os
+import socket
+import sys
+
+import numpy as np
+import pytest
+import torch
+import torch.distributed as dist
+import torch.multiprocessing as mp
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+ROOT = os.path.dirname(HERE)
+
+
+def _setup_path():
+    for p in (ROOT, os.path.join(ROOT, "gaussian-splatting-own_amd"), HERE):
+        if p not in sys.path:
+            sys.path.insert(0, p)
+
+
+def _scene():
+    _setup_path()
+    import oracle
+    from gsplat_host.cameras import orbit_camera
+    from gsplat_host.synthetic import make_cloud
+    cloud = make_cloud(600, sh_degree=1, seed=4, coeffs=4)
+    cams = [orbit_camera(96, 64, angle_deg=45.0 * k) for k in range(4)]
+    targets = [torch.rand(3, 64, 96, generator=torch.Generator().manual_seed(10 + k)) for k in range(4)]
+    o = oracle.Oracle(np.float32, threads=1)
+
+    def render_view(cam):
+        s = oracle.Settings(64, 96, math.tan(cam.FoVx / 2), math.tan(cam.FoVy / 2), np.zeros(3, np.float32), 1.0,
+                            cam.world_view_transform.numpy(), cam.full_proj_transform.numpy(), 1,
+                            cam.camera_center.numpy())
+        out = o.forward(s, means3D=cloud.xyz.numpy(), opacities=cloud.opacity.numpy(), scales=cloud.scaling.numpy(),
+                        rotations=cloud.rotation.numpy(), shs=cloud.features.numpy(), want_margin=False)
+        return torch.from_numpy(out["color"])
+    return cams, targets, render_view
+
+
+def _worker(rank, world, port, q):
+    _setup_path()
+    from gsplat_host.loss import photometric_loss
+    from gsplat_host.multiview import multiview_step
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    cams, targets, render_view = _scene()
+    loss, mine = multiview_step(cams, render_view, photometric_loss, targets, rank=rank, world=world, backward=False)
+    q.put((rank, float(loss), mine))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_view_sharding_is_a_partition():
+    _setup_path()
+    from gsplat_host.multiview import views_for_rank
+    for world in (1, 2, 3, 8):
+        seen = sorted(v for r in range(world) for v in views_for_rank(8, r, world))
+        assert seen == list(range(8))
+    assert views_for_rank(8, 3, 8) == [3]
+    assert views_for_rank(2, 5, 8) == []
+    with pytest.raises(ValueError):
+        views_for_rank(8, 8, 8)
+
+
+def test_two_ranks_match_one(tmp_path):
+    _setup_path()
+    from gsplat_host.loss import photometric_loss
+    from gsplat_host.multiview import multiview_step
+    cams, targets, render_view = _scene()
+    want, mine = multiview_step(cams, render_view, photometric_loss, targets, rank=0, world=1, backward=False)
+    assert mine == [0, 1, 2, 3]
+
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        port = s.getsockname()[1]
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    procs = [ctx.Process(target=_worker, args=(r, 2, port, q)) for r in range(2)]
+    for p in procs:
+        p.start()
+    results = sorted(q.get(timeout=120) for _ in procs)
+    for p in procs:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    assert results[0][2] == [0, 2] and results[1][2] == [1, 3]
+    assert abs(results[0][1] - results[1][1]) < 1e-7          # both ranks hold the same reduced loss
+    assert abs(results[0][1] - float(want)) < 1e-6
