@@ -16,6 +16,7 @@ namespace {
 
 constexpr int kBatch = 256;
 constexpr float kLog2e = 1.4426950408889634f;
+constexpr float kLn2 = 0.6931471805599453f;
 
 struct Pixel {
   int x, y;       // pixel coordinates
@@ -50,6 +51,31 @@ __device__ __forceinline__ unsigned long long lds_mask(const unsigned long long*
   const unsigned lo = __builtin_amdgcn_readfirstlane((unsigned)v);
   const unsigned hi = __builtin_amdgcn_readfirstlane((unsigned)(v >> 32));
   return ((unsigned long long)hi << 32) | lo;
+}
+
+// Exponent of the Gaussian in the log2 domain, la*dx^2 + lc*dy^2 + lb*dx*dy with
+// (la, lb, lc) = (-A/2, -B, -C/2) * log2(e).  Forward and backward MUST take the
+// same skip / keep decisions per (splat, pixel), so both call this one function
+// and the rounding sequence is pinned with explicit fma.
+__device__ __forceinline__ float gauss_exponent(float la, float lb, float lc, float dx, float dy) {
+  return fmaf(lb * dx, dy, fmaf(la * dx, dx, (lc * dy) * dy));
+}
+
+// What a staging thread publishes about one splat.
+struct Staged {
+  float4 geo;   // x, y, la, lb
+  float4 col;   // lc, opacity, r, g
+  float blue;
+};
+
+__device__ __forceinline__ Staged stage_record(const uint4 r0, const uint4 r1, const uint4 r2) {
+  Staged s;
+  s.geo = make_float4(__uint_as_float(r0.x), __uint_as_float(r0.y), -0.5f * kLog2e * __uint_as_float(r1.x),
+                      -kLog2e * __uint_as_float(r1.y));
+  s.col = make_float4(-0.5f * kLog2e * __uint_as_float(r1.z), __uint_as_float(r1.w), __uint_as_float(r2.x),
+                      __uint_as_float(r2.y));
+  s.blue = __uint_as_float(r2.z);
+  return s;
 }
 
 // ---------------------------------------------------------------------------
@@ -90,10 +116,10 @@ __global__ void __launch_bounds__(256) blend_fwd_kernel(int W, int H, const uint
       const uint4 r0 = rec[0], r1 = rec[1], r2 = rec[2];
       const float sx = __uint_as_float(r0.x), sy = __uint_as_float(r0.y);
       qm = quadrant_mask(sx, sy, __uint_as_float(r0.z), __uint_as_float(r0.w), tx0, ty0);
-      s_geo[threadIdx.x] = make_float4(sx, sy, -0.5f * kLog2e * __uint_as_float(r1.x), -kLog2e * __uint_as_float(r1.y));
-      s_col[threadIdx.x] = make_float4(-0.5f * kLog2e * __uint_as_float(r1.z), __uint_as_float(r1.w),
-                                       __uint_as_float(r2.x), __uint_as_float(r2.y));
-      s_blue[threadIdx.x] = __uint_as_float(r2.z);
+      const Staged sp = stage_record(r0, r1, r2);
+      s_geo[threadIdx.x] = sp.geo;
+      s_col[threadIdx.x] = sp.col;
+      s_blue[threadIdx.x] = sp.blue;
     }
 #pragma unroll
     for (int q = 0; q < 4; q++) {
@@ -111,7 +137,7 @@ __global__ void __launch_bounds__(256) blend_fwd_kernel(int W, int H, const uint
           const float4 ga = s_geo[j];
           const float4 co = s_col[j];
           const float dx = ga.x - pxf, dy = ga.y - pyf;
-          const float p = (ga.z * dx) * dx + (co.x * dy) * dy + (ga.w * dx) * dy;   // log2-domain exponent
+          const float p = gauss_exponent(ga.z, ga.w, co.x, dx, dy);
           if (!done && p <= 0.0f) {
             const float alpha = fminf(GSR_ALPHA_MAX, co.y * __builtin_amdgcn_exp2f(p));
             if (alpha >= GSR_ALPHA_MIN) {
@@ -172,8 +198,8 @@ __global__ void __launch_bounds__(256) blend_bwd_kernel(int W, int H, const uint
                                                         const uint32_t* __restrict__ n_contrib,
                                                         const float* __restrict__ dL_dpix,
                                                         float* __restrict__ dL_dsplat) {
-  __shared__ float4 s_geo[kBatch];   // x, y, A, B
-  __shared__ float4 s_col[kBatch];   // C, opacity, r, g
+  __shared__ float4 s_geo[kBatch];   // x, y, -A/2*log2e, -B*log2e
+  __shared__ float4 s_col[kBatch];   // -C/2*log2e, opacity, r, g
   __shared__ float s_blue[kBatch];
   __shared__ uint32_t s_id[kBatch];
   __shared__ unsigned long long s_mask[4][4];
@@ -216,10 +242,10 @@ __global__ void __launch_bounds__(256) blend_bwd_kernel(int W, int H, const uint
       const uint4 r0 = rec[0], r1 = rec[1], r2 = rec[2];
       const float sx = __uint_as_float(r0.x), sy = __uint_as_float(r0.y);
       qm = quadrant_mask(sx, sy, __uint_as_float(r0.z), __uint_as_float(r0.w), tx0, ty0);
-      s_geo[threadIdx.x] = make_float4(sx, sy, __uint_as_float(r1.x), __uint_as_float(r1.y));
-      s_col[threadIdx.x] = make_float4(__uint_as_float(r1.z), __uint_as_float(r1.w), __uint_as_float(r2.x),
-                                       __uint_as_float(r2.y));
-      s_blue[threadIdx.x] = __uint_as_float(r2.z);
+      const Staged sp = stage_record(r0, r1, r2);
+      s_geo[threadIdx.x] = sp.geo;
+      s_col[threadIdx.x] = sp.col;
+      s_blue[threadIdx.x] = sp.blue;
       s_id[threadIdx.x] = g;
     }
 #pragma unroll
@@ -240,11 +266,11 @@ __global__ void __launch_bounds__(256) blend_bwd_kernel(int W, int H, const uint
         const float4 ga = s_geo[j];
         const float4 co = s_col[j];
         const float dx = ga.x - pxf, dy = ga.y - pyf;
-        const float power = -0.5f * (ga.z * dx * dx + co.x * dy * dy) - ga.w * dx * dy;
+        const float p = gauss_exponent(ga.z, ga.w, co.x, dx, dy);   // identical to the forward's
         float g_mx = 0.f, g_my = 0.f, g_a = 0.f, g_b = 0.f, g_c = 0.f, g_o = 0.f, g_r = 0.f, g_g = 0.f, g_bl = 0.f;
         bool hit = false;
-        if (pos < last && power <= 0.0f) {
-          const float G = __builtin_amdgcn_exp2f(power * kLog2e);
+        if (pos < last && p <= 0.0f) {
+          const float G = __builtin_amdgcn_exp2f(p);
           const float alpha = fminf(GSR_ALPHA_MAX, co.y * G);
           if (alpha >= GSR_ALPHA_MIN) {
             hit = true;
@@ -263,8 +289,9 @@ __global__ void __launch_bounds__(256) blend_bwd_kernel(int W, int H, const uint
             dL_dalpha += (-Tf * inv) * bg_dot;
             const float dL_dG = co.y * dL_dalpha;
             const float gdx = G * dx, gdy = G * dy;
-            const float dG_ddelx = -gdx * ga.z - gdy * ga.w;
-            const float dG_ddely = -gdy * co.x - gdx * ga.w;
+            // -A = 2 la / log2e, -B = lb / log2e, -C = 2 lc / log2e
+            const float dG_ddelx = kLn2 * (2.0f * gdx * ga.z + gdy * ga.w);
+            const float dG_ddely = kLn2 * (2.0f * gdy * co.x + gdx * ga.w);
             g_mx = dL_dG * dG_ddelx * ddelx_dx;
             g_my = dL_dG * dG_ddely * ddely_dy;
             g_a = -0.5f * gdx * dx * dL_dG;

@@ -111,13 +111,12 @@ def test_backward(oracle32, name):
     cloud, cam, bg, mod, s_cpu, s_gpu, cn, ref, st = _run_case(oracle32, name)
     rng = np.random.default_rng(3)
     dL = rng.standard_normal((3, cam.image_height, cam.image_width)).astype(np.float32)
-    # backward of the oracle FROM THE GPU's forward state where the two may legitimately differ
-    # (n_contrib / final_T of borderline pixels), so that only the backward kernels are compared
-    fw = dict(ref["fwd"])
-    fw["final_T"] = st.final_T.cpu().numpy()
-    fw["n_contrib"] = st.n_contrib.cpu().numpy().view(np.uint32)
-    state = dict(pre=ref["pre"], bin=ref["bin"], fwd=fw)
-    g_ref = oracle32.backward(s_cpu, state, dL, cn["means3D"], scales=cn["scales"], rotations=cn["rotations"],
+    # Each side runs its backward from its OWN forward state.  Pixels whose forward decisions may
+    # legitimately differ in fp32 (oracle margin below MARGIN_SAFE, ~0.1-0.2 % of pixels) get a zero
+    # loss gradient, so that what is compared is the backward arithmetic on identical decisions.
+    safe = ref["fwd"]["margin"] >= MARGIN_SAFE
+    dL *= safe[None].astype(np.float32)
+    g_ref = oracle32.backward(s_cpu, ref, dL, cn["means3D"], scales=cn["scales"], rotations=cn["rotations"],
                               shs=cn["shs"])
     c = cloud.to("cuda")
     dLg = torch.from_numpy(dL).cuda()
@@ -131,12 +130,12 @@ def test_backward(oracle32, name):
                           ("opacity", ds[:, 5], bb["dL_dopacity"]), ("color", ds[:, 6:9], bb["dL_dcolor"])]:
         e = _rel_err(got, want)
         print(name, "blend_bwd", nm, "rel err %.2e" % e, flush=True)
-        assert e < 2e-4, (nm, e)
+        assert e < 2e-5, (nm, e)
     for nm in ("means3D", "means2D", "shs", "opacities", "scales", "rotations"):
         got, want = g[nm].cpu().numpy(), g_ref[nm]
         e = _rel_err(got, want.reshape(got.shape))
         print(name, "grad", nm, "rel err %.2e" % e, flush=True)
-        assert e < 3e-4, (nm, e)
+        assert e < 3e-5, (nm, e)
         assert np.isfinite(got).all()
 
 
