@@ -305,12 +305,14 @@ __global__ void __launch_bounds__(256) blend_bwd_kernel(int W, int H, const uint
         g_a = wave_sum_hi(g_a); g_b = wave_sum_hi(g_b); g_c = wave_sum_hi(g_c);
         g_o = wave_sum_hi(g_o);
         g_r = wave_sum_hi(g_r); g_g = wave_sum_hi(g_g); g_bl = wave_sum_hi(g_bl);
-        if (lane == 63) {
-          float* dst = dL_dsplat + (size_t)s_id[j] * GSR_GRAD_WORDS;
-          atomicAdd(dst + 0, g_mx); atomicAdd(dst + 1, g_my);
-          atomicAdd(dst + 2, g_a); atomicAdd(dst + 3, g_b); atomicAdd(dst + 4, g_c);
-          atomicAdd(dst + 5, g_o);
-          atomicAdd(dst + 6, g_r); atomicAdd(dst + 7, g_g); atomicAdd(dst + 8, g_bl);
+        // lanes 48..56 hold all nine totals; lane 48+k adds sum k: one wave-instruction,
+        // nine consecutive dwords of one 64-byte row = one atomic request
+        const int k = lane - 48;
+        if (k >= 0 && k < 9) {
+          float v = g_mx;
+          v = k == 1 ? g_my : v; v = k == 2 ? g_a : v; v = k == 3 ? g_b : v; v = k == 4 ? g_c : v;
+          v = k == 5 ? g_o : v; v = k == 6 ? g_r : v; v = k == 7 ? g_g : v; v = k == 8 ? g_bl : v;
+          atomicAdd(dL_dsplat + (size_t)s_id[j] * GSR_GRAD_WORDS + k, v);
         }
       }
     }

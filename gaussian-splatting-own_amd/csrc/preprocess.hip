@@ -310,7 +310,7 @@ __global__ void __launch_bounds__(kBlock) preprocess_bwd_kernel(BwdArgs a) {
   if (i >= a.P) return;
   const uint4 r3 = reinterpret_cast<const uint4*>(a.records)[(size_t)i * 4 + 3];
   const bool vis = (int)r3.z > 0;
-  const float4* gsp = reinterpret_cast<const float4*>(a.dL_dsplat) + (size_t)i * 3;
+  const float4* gsp = reinterpret_cast<const float4*>(a.dL_dsplat) + (size_t)i * (GSR_GRAD_WORDS / 4);
   float4 g0 = make_float4(0, 0, 0, 0), g1 = g0, g2 = g0;
   if (vis) { g0 = gsp[0]; g1 = gsp[1]; g2 = gsp[2]; }
   // g0 = (dmean2D.x, dmean2D.y, dA, dB); g1 = (dC, dopacity, dr, dg); g2 = (db, -, -, -)

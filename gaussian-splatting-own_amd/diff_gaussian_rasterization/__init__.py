@@ -31,7 +31,7 @@ _LIB_PATH = os.path.join(_HERE, "libgsr_hip.so")
 
 TILE = 16
 REC_WORDS = 16
-GRAD_WORDS = 12
+GRAD_WORDS = 16
 
 
 def _load():
@@ -233,7 +233,7 @@ def rasterize_forward(s: GaussianRasterizationSettings, means3D, opacities, shs=
 
 
 def blend_backward(st: ForwardState, grad_color: torch.Tensor) -> torch.Tensor:
-    """dL/dpixels (3,H,W) -> per-Gaussian sums (P,12); see GSR_GRAD_WORDS in gsr.h."""
+    """dL/dpixels (3,H,W) -> per-Gaussian sums (P,16); see GSR_GRAD_WORDS in gsr.h."""
     grad_color = _f32(grad_color, "grad_color")
     dsplat = torch.zeros((st.P, GRAD_WORDS), dtype=torch.float32, device=grad_color.device)
     if st.P > 0 and st.num_rendered > 0:

@@ -138,13 +138,15 @@ int gsr_blend_fwd(int W, int H, const uint32_t* ranges, const uint32_t* point_li
                   uint32_t* n_contrib, void* stream);
 
 /* ---- Stage 4: blend backward ---------------------------------------------
- * dL_dpix (3,H,W) -> per-Gaussian sums, accumulated into dL_dsplat (P,12) fp32
- * which the caller zero-fills first: words 0-1 dL/dmean2D in NDC-scaled units
+ * dL_dpix (3,H,W) -> per-Gaussian sums, accumulated into dL_dsplat (P,16) fp32
+ * (one 64-byte-aligned row per Gaussian, so that the nine sums of a splat leave
+ * a wave as ONE atomic request) which the caller zero-fills first and which
+ * must be 64-byte aligned: words 0-1 dL/dmean2D in NDC-scaled units
  * (x by W/2, y by H/2; this is what the reference reads from the .grad of its
  * screenspace_points sink, gaussian_renderer/__init__.py:26-30,
  * scene/gaussian_model.py:405-407), 2-4 dL/d(conic A,B,C), 5 dL/dopacity,
- * 6-8 dL/dcolour, 9-11 unused. */
-#define GSR_GRAD_WORDS 12
+ * 6-8 dL/dcolour, 9-15 unused. */
+#define GSR_GRAD_WORDS 16
 int gsr_blend_bwd(int W, int H, const uint32_t* ranges, const uint32_t* point_list,
                   const uint32_t* records, const float* bg, const float* final_T,
                   const uint32_t* n_contrib, const float* dL_dpix, float* dL_dsplat,
