@@ -44,13 +44,13 @@ def _load():
     lib.gsr_bin_prepare_bytes.restype = C.c_size_t
     lib.gsr_bin_prepare_bytes.argtypes = [C.c_int]
     lib.gsr_bin_emit_bytes.restype = C.c_size_t
-    lib.gsr_bin_emit_bytes.argtypes = [C.c_int, C.c_uint32, C.c_int, C.c_int]
+    lib.gsr_bin_emit_bytes.argtypes = [C.c_int, C.c_uint32, C.c_uint32, C.c_int, C.c_int]
     vp, ci, cf = C.c_void_p, C.c_int, C.c_float
     lib.gsr_preprocess_fwd.argtypes = [ci, ci, ci, vp, vp, cf, vp, vp, vp, vp, vp, vp, vp, vp, ci, ci, cf, cf, ci,
                                        vp, vp, vp, vp, vp]
     lib.gsr_mark_visible.argtypes = [ci, vp, vp, vp, vp]
-    lib.gsr_bin_prepare.argtypes = [ci, vp, vp, vp, vp, vp, C.c_size_t, vp]
-    lib.gsr_bin_emit.argtypes = [ci, C.c_uint32, ci, ci, vp, vp, vp, vp, vp, vp, vp, C.c_size_t, vp]
+    lib.gsr_bin_prepare.argtypes = [ci, vp, vp, vp, vp, vp, vp, vp, C.c_size_t, vp]
+    lib.gsr_bin_emit.argtypes = [ci, C.c_uint32, C.c_uint32, ci, ci, vp, vp, vp, vp, vp, vp, vp, C.c_size_t, vp]
     lib.gsr_blend_fwd.argtypes = [ci, ci, vp, vp, vp, vp, vp, vp, vp, vp]
     lib.gsr_blend_bwd.argtypes = [ci, ci, vp, vp, vp, vp, vp, vp, vp, vp, vp]
     lib.gsr_preprocess_bwd.argtypes = [ci, ci, ci, vp, vp, cf, vp, vp, vp, vp, vp, vp, ci, ci, cf, cf, vp, vp,
@@ -205,25 +205,28 @@ def rasterize_forward(s: GaussianRasterizationSettings, means3D, opacities, shs=
     st.final_T = torch.empty((H, W), dtype=torch.float32, device=dev)
     st.n_contrib = torch.empty((H, W), **u32)
     st.tile_ids_sorted = None
-    N = 0
+    N = NC = 0
     if P > 0:
-        _run("preprocess_fwd", _lib.gsr_preprocess_fwd, P, st.D, st.M, _ptr(means3D), _ptr(scales), float(s.scale_modifier), _ptr(rotations), _ptr(opacities),
-            _ptr(shs), _ptr(colors_precomp), _ptr(cov3D_precomp), _ptr(st.view), _ptr(st.proj), _ptr(st.campos),
-            W, H, float(s.tanfovx), float(s.tanfovy), int(bool(s.prefiltered)), _ptr(st.records), _ptr(st.radii),
-            _ptr(st.tiles_touched), _ptr(st.depth_keys), stream)
+        _run("preprocess_fwd", _lib.gsr_preprocess_fwd, P, st.D, st.M, _ptr(means3D), _ptr(scales),
+             float(s.scale_modifier), _ptr(rotations), _ptr(opacities), _ptr(shs), _ptr(colors_precomp),
+             _ptr(cov3D_precomp), _ptr(st.view), _ptr(st.proj), _ptr(st.campos), W, H, float(s.tanfovx),
+             float(s.tanfovy), int(bool(s.prefiltered)), _ptr(st.records), _ptr(st.radii), _ptr(st.tiles_touched),
+             _ptr(st.depth_keys), stream)
         nb = _lib.gsr_bin_prepare_bytes(P)
         scratch = torch.empty((nb,), dtype=torch.uint8, device=dev)
-        _run("bin_prepare", _lib.gsr_bin_prepare, P, _ptr(st.depth_keys), _ptr(st.tiles_touched), _ptr(st.order), _ptr(st.offsets),
-                                    _ptr(scratch), nb, stream)
-        N = int(st.offsets[P - 1].item()) & 0xFFFFFFFF     # the pipeline's one host read-back
+        totals = torch.empty((2,), **u32)
+        _run("bin_prepare", _lib.gsr_bin_prepare, P, _ptr(st.records), _ptr(st.depth_keys), _ptr(st.tiles_touched),
+             _ptr(st.order), _ptr(st.offsets), _ptr(totals), _ptr(scratch), nb, stream)
+        n_nc = totals.tolist()                              # the pipeline's one host read-back
+        N, NC = n_nc[0] & 0xFFFFFFFF, n_nc[1] & 0xFFFFFFFF
     st.num_rendered = N
     st.point_list = torch.empty((max(N, 1),), **u32)
     if keep_tile_ids:
         st.tile_ids_sorted = torch.empty((max(N, 1),), **u32)
-    nb = _lib.gsr_bin_emit_bytes(P, N, W, H)
+    nb = _lib.gsr_bin_emit_bytes(P, N, NC, W, H)
     scratch = torch.empty((nb,), dtype=torch.uint8, device=dev)
-    _run("bin_emit", _lib.gsr_bin_emit, P, N, W, H, _ptr(st.records), _ptr(st.order), _ptr(st.offsets), _ptr(st.point_list),
-                             _ptr(st.ranges), _ptr(st.tile_ids_sorted), _ptr(scratch), nb, stream)
+    _run("bin_emit", _lib.gsr_bin_emit, P, N, NC, W, H, _ptr(st.records), _ptr(st.order), _ptr(st.offsets),
+         _ptr(st.point_list), _ptr(st.ranges), _ptr(st.tile_ids_sorted), _ptr(scratch), nb, stream)
     _run("blend_fwd", _lib.gsr_blend_fwd, W, H, _ptr(st.ranges), _ptr(st.point_list), _ptr(st.records), _ptr(st.bg),
                               _ptr(st.color), _ptr(st.final_T), _ptr(st.n_contrib), stream)
     st.point_list = st.point_list[:N]

@@ -104,26 +104,30 @@ int gsr_mark_visible(int P, const float* means3D, const float* viewmatrix, uint8
  * covers it, ordered front to back: the result of the module's
  * duplicateWithKeys -> 64-bit (tile | depth) radix sort -> identifyTileRanges
  * chain, bit for bit (ties in (tile, depth) keep ascending Gaussian index).
- * It is computed as a stable 32-bit depth sort of the P Gaussians followed by
- * a stable sort of the tile instances by tile id, which moves ~4x fewer bytes.
+ * No per-tile instance is sorted: the Gaussians are depth-sorted (P keys), one
+ * entry per CELL (tile row x strip of 16 tiles) of each rectangle is sorted by
+ * cell id (NC ~ N/6 entries), and each cell list is expanded in order into its
+ * tiles.  Every step is stable, so the lists equal the 64-bit sort's.
  *
- * gsr_bin_prepare: depth-sorts the Gaussians and prefix-sums tiles_touched in
- * that order.  order (P) uint32 = Gaussian indices front to back;
- * offsets (P) uint32 = inclusive prefix sum; *(offsets + P - 1) is the number
- * of tile instances N, which the caller reads back to size gsr_bin_emit. */
+ * gsr_bin_prepare: depth-sorts the Gaussians, prefix-sums the number of cells
+ * each touches in that order, and totals the tile instances.
+ * order (P) uint32 = Gaussian indices front to back; cell_offsets (P) uint32 =
+ * inclusive prefix sum of cells touched; totals (2) uint32 = { N = number of
+ * tile instances, NC = number of cell entries }, which the caller reads back
+ * (the pipeline's one host read-back) to size gsr_bin_emit. */
 size_t gsr_bin_prepare_bytes(int P);
-int gsr_bin_prepare(int P, const uint32_t* depth_keys, const uint32_t* tiles_touched,
-                    uint32_t* order, uint32_t* offsets, void* scratch, size_t scratch_bytes,
-                    void* stream);
+int gsr_bin_prepare(int P, const uint32_t* records, const uint32_t* depth_keys,
+                    const uint32_t* tiles_touched, uint32_t* order, uint32_t* cell_offsets,
+                    uint32_t* totals, void* scratch, size_t scratch_bytes, void* stream);
 
 /* gsr_bin_emit: point_list (N) uint32 = Gaussian index per sorted instance;
  * ranges (tiles,2) uint32 = [start,end) into point_list per tile, (0,0) for
  * empty tiles.  tile_ids_sorted (N) uint32 is optional (may be NULL): the tile
  * id of each sorted instance, from which the module's 64-bit sort keys are
  * (tile << 32) | depth_key[point_list]. */
-size_t gsr_bin_emit_bytes(int P, uint32_t N, int W, int H);
-int gsr_bin_emit(int P, uint32_t N, int W, int H, const uint32_t* records,
-                 const uint32_t* order, const uint32_t* offsets, uint32_t* point_list,
+size_t gsr_bin_emit_bytes(int P, uint32_t N, uint32_t NC, int W, int H);
+int gsr_bin_emit(int P, uint32_t N, uint32_t NC, int W, int H, const uint32_t* records,
+                 const uint32_t* order, const uint32_t* cell_offsets, uint32_t* point_list,
                  uint32_t* ranges, uint32_t* tile_ids_sorted, void* scratch,
                  size_t scratch_bytes, void* stream);
 
