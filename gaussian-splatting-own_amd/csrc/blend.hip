@@ -173,21 +173,30 @@ __global__ void __launch_bounds__(256) blend_fwd_kernel(int W, int H, const uint
 // ---------------------------------------------------------------------------
 // backward
 // ---------------------------------------------------------------------------
-template <int CTRL, int ROW_MASK>
+template <int CTRL>
 __device__ __forceinline__ float dpp_add(float v) {
-  const int moved = __builtin_amdgcn_update_dpp(0, __float_as_int(v), CTRL, ROW_MASK, 0xf, false);
+  const int moved = __builtin_amdgcn_update_dpp(0, __float_as_int(v), CTRL, 0xf, 0xf, false);
   return v + __int_as_float(moved);
 }
 
-// Sum over the 64 lanes; the total is valid in lanes 48..63.
-__device__ __forceinline__ float wave_sum_hi(float v) {
-  v = dpp_add<0xB1, 0xf>(v);    // quad_perm [1,0,3,2]
-  v = dpp_add<0x4E, 0xf>(v);    // quad_perm [2,3,0,1]
-  v = dpp_add<0x141, 0xf>(v);   // row_half_mirror
-  v = dpp_add<0x140, 0xf>(v);   // row_mirror: every lane of a row holds the row sum
-  v = dpp_add<0x142, 0xa>(v);   // row_bcast:15 into rows 1 and 3
-  v = dpp_add<0x143, 0xc>(v);   // row_bcast:31 into rows 2 and 3
+// Sum over each row of 16 lanes, left in every lane of the row (4 fused v_add_f32_dpp).
+__device__ __forceinline__ float row_sum(float v) {
+  v = dpp_add<0xB1>(v);    // quad_perm [1,0,3,2]
+  v = dpp_add<0x4E>(v);    // quad_perm [2,3,0,1]
+  v = dpp_add<0x141>(v);   // row_half_mirror
+  v = dpp_add<0x140>(v);   // row_mirror
   return v;
+}
+
+typedef unsigned uint2v __attribute__((ext_vector_type(2)));
+
+// Sum over the four rows of a wave, lane-wise: lane l ends with v[l%16] summed over the rows.
+// v_permlane16_swap / v_permlane32_swap exchange odd and even rows, then the two 32-lane halves.
+__device__ __forceinline__ float sum_across_rows(float v) {
+  uint2v r = __builtin_amdgcn_permlane16_swap(__float_as_uint(v), __float_as_uint(v), false, false);
+  v = __uint_as_float(r.x) + __uint_as_float(r.y);
+  r = __builtin_amdgcn_permlane32_swap(__float_as_uint(v), __float_as_uint(v), false, false);
+  return __uint_as_float(r.x) + __uint_as_float(r.y);
 }
 
 __global__ void __launch_bounds__(256) blend_bwd_kernel(int W, int H, const uint2* __restrict__ ranges,
@@ -301,19 +310,20 @@ __global__ void __launch_bounds__(256) blend_bwd_kernel(int W, int H, const uint
           }
         }
         if (__ballot(hit) == 0ull) continue;
-        g_mx = wave_sum_hi(g_mx); g_my = wave_sum_hi(g_my);
-        g_a = wave_sum_hi(g_a); g_b = wave_sum_hi(g_b); g_c = wave_sum_hi(g_c);
-        g_o = wave_sum_hi(g_o);
-        g_r = wave_sum_hi(g_r); g_g = wave_sum_hi(g_g); g_bl = wave_sum_hi(g_bl);
-        // lanes 48..56 hold all nine totals; lane 48+k adds sum k: one wave-instruction,
-        // nine consecutive dwords of one 64-byte row = one atomic request
-        const int k = lane - 48;
-        if (k >= 0 && k < 9) {
-          float v = g_mx;
-          v = k == 1 ? g_my : v; v = k == 2 ? g_a : v; v = k == 3 ? g_b : v; v = k == 4 ? g_c : v;
-          v = k == 5 ? g_o : v; v = k == 6 ? g_r : v; v = k == 7 ? g_g : v; v = k == 8 ? g_bl : v;
-          atomicAdd(dL_dsplat + (size_t)s_id[j] * GSR_GRAD_WORDS + k, v);
-        }
+        // Nine sums over 64 lanes: reduce each within its row of 16 (every lane of a row then
+        // holds the nine row sums), let lane k of every row keep sum k, and add the four rows
+        // lane-wise.  Lanes 0..8 then issue ONE wave-instruction on nine consecutive dwords of
+        // one 64-byte row = one atomic request.
+        g_mx = row_sum(g_mx); g_my = row_sum(g_my);
+        g_a = row_sum(g_a); g_b = row_sum(g_b); g_c = row_sum(g_c);
+        g_o = row_sum(g_o);
+        g_r = row_sum(g_r); g_g = row_sum(g_g); g_bl = row_sum(g_bl);
+        const int k = lane & 15;
+        float v = g_mx;
+        v = k == 1 ? g_my : v; v = k == 2 ? g_a : v; v = k == 3 ? g_b : v; v = k == 4 ? g_c : v;
+        v = k == 5 ? g_o : v; v = k == 6 ? g_r : v; v = k == 7 ? g_g : v; v = k == 8 ? g_bl : v;
+        v = sum_across_rows(v);
+        if (lane < 9) atomicAdd(dL_dsplat + (size_t)s_id[j] * GSR_GRAD_WORDS + lane, v);
       }
     }
   }
