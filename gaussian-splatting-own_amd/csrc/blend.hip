@@ -99,12 +99,16 @@ __global__ void __launch_bounds__(256) blend_fwd_kernel(int W, int H, const uint
   const int total = (int)(range.y - range.x);
   const int rounds = (total + kBatch - 1) / kBatch;
 
-  bool done = !px.inside;
+  // Per-pixel state lives in VGPRs only and the splat body is straight-line, predicated code:
+  // a pixel that is finished (live == 0) or skips a splat simply blends with alpha = 0, which
+  // leaves T and the colour sums bit for bit unchanged.  Branching per lane instead costs a
+  // dozen scalar mask instructions per splat, and the scalar unit is shared by the CU's 4 SIMDs.
+  float live = px.inside ? 1.0f : 0.0f;
   float T = 1.0f, C0 = 0.f, C1 = 0.f, C2 = 0.f;
   uint32_t last = 0;
 
   for (int b = 0; b < rounds; b++) {
-    const bool wave_done = __ballot(!done) == 0ull;
+    const bool wave_done = __ballot(live != 0.0f) == 0ull;
     if (__syncthreads_and(wave_done)) break;   // also fences the previous batch's LDS reads
 
     // stage one batch
@@ -132,30 +136,30 @@ __global__ void __launch_bounds__(256) blend_fwd_kernel(int W, int H, const uint
       for (int sw = 0; sw < 4; sw++) {
         unsigned long long m = lds_mask(&s_mask[px.quad][sw]);
         while (m) {
-          const int j = sw * 64 + (__ffsll((long long)m) - 1);
-          m &= m - 1;
+          const int bit = __ffsll((long long)m) - 1;
+          m &= ~(1ull << bit);
+          const int j = sw * 64 + bit;
           const float4 ga = s_geo[j];
           const float4 co = s_col[j];
+          const float blue = s_blue[j];
           const float dx = ga.x - pxf, dy = ga.y - pyf;
           const float p = gauss_exponent(ga.z, ga.w, co.x, dx, dy);
-          if (!done && p <= 0.0f) {
-            const float alpha = fminf(GSR_ALPHA_MAX, co.y * __builtin_amdgcn_exp2f(p));
-            if (alpha >= GSR_ALPHA_MIN) {
-              const float test_T = T * (1.0f - alpha);
-              if (test_T < GSR_T_STOP) {
-                done = true;
-              } else {
-                const float w = alpha * T;
-                C0 += co.z * w;
-                C1 += co.w * w;
-                C2 += s_blue[j] * w;
-                T = test_T;
-                last = (uint32_t)(b * kBatch + j + 1);
-              }
-            }
-          }
+          float alpha = fminf(GSR_ALPHA_MAX, co.y * __builtin_amdgcn_exp2f(p));
+          alpha = p <= 0.0f ? alpha : 0.0f;
+          alpha = alpha >= GSR_ALPHA_MIN ? alpha : 0.0f;
+          alpha *= live;
+          if (__ballot(alpha > 0.0f) == 0ull) continue;       // no pixel of the quadrant takes this splat
+          const float test_T = T * (1.0f - alpha);            // alpha == 0: exactly T
+          const bool stop = test_T < GSR_T_STOP;               // implies alpha > 0 (T >= T_STOP while live)
+          const float w = stop ? 0.0f : alpha * T;
+          live = stop ? 0.0f : live;
+          T = stop ? T : test_T;
+          C0 = fmaf(co.z, w, C0);
+          C1 = fmaf(co.w, w, C1);
+          C2 = fmaf(blue, w, C2);
+          last = w > 0.0f ? (uint32_t)(b * kBatch + j + 1) : last;
         }
-        if (__ballot(!done) == 0ull) break;
+        if (__ballot(live != 0.0f) == 0ull) break;
       }
     }
   }
