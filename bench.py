@@ -76,13 +76,16 @@ def main():
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
-    if world > 1:
-        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group("nccl", rank=rank, world_size=world)
-    if args.gpus != world and rank == 0 and world > 1:
-        print(f"warning: --gpus {args.gpus} but WORLD_SIZE {world}", file=sys.stderr)
     torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
+    # under torch.distributed.run (RANK set) the process group is always formed, also for one
+    # rank, so that the RCCL path is the one exercised whatever N is
+    use_dist = world > 1 or ("RANK" in os.environ and "MASTER_PORT" in os.environ)
+    if use_dist:
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
+    if args.gpus != world and rank == 0:
+        print(f"warning: --gpus {args.gpus} but WORLD_SIZE {world}", file=sys.stderr)
 
     import diff_gaussian_rasterization as dgr
     from gsplat_host.cameras import orbit_camera
@@ -115,7 +118,7 @@ def main():
             fwd_events.append((e0, e1))
         loss = photometric_loss(out["render"], gt)
         loss.backward()
-        if world > 1:
+        if use_dist:
             lv = loss.detach().clone()
             dist.all_reduce(lv)                                       # RCCL over xGMI: one fp32 scalar
             lv /= world
@@ -123,7 +126,7 @@ def main():
 
     def barrier():
         torch.cuda.synchronize()
-        if world > 1:
+        if use_dist:
             dist.barrier()
         torch.cuda.synchronize()
 
@@ -138,12 +141,12 @@ def main():
     elapsed = time.perf_counter() - t0
     dgr.set_stage_timer(None)
 
-    if world > 1:
+    if use_dist:
         t = torch.tensor([elapsed], device=dev, dtype=torch.float64)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed = float(t.item())
     render_ms = sum(a.elapsed_time(b) for a, b in fwd_events) / len(fwd_events)
-    if world > 1:
+    if use_dist:
         t = torch.tensor([render_ms], device=dev, dtype=torch.float64)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         render_ms = float(t.item())
@@ -176,7 +179,7 @@ def main():
         if world == 1 and not args.no_cpu_baseline:
             line["cpu_baseline"] = cpu_baseline(cloud, W, H, deg)
         print(json.dumps(line), flush=True)
-    if world > 1:
+    if use_dist:
         dist.barrier()
         dist.destroy_process_group()
 

@@ -279,9 +279,14 @@ __global__ void __launch_bounds__(kBlock) fill_tile_ids_kernel(const uint32_t* _
   for (uint32_t i = b + threadIdx.x; i < e; i += kBlock) tile_ids[i] = t;
 }
 
+// rocPRIM switches to a block sort + log2(P/block) merge passes below 2^20 items; for the
+// ~1M depth keys of a large scene four Onesweep radix passes move far fewer bytes.
+using DepthSortConfig =
+    rocprim::radix_sort_config<rocprim::default_config, rocprim::default_config, rocprim::default_config, (1u << 16)>;
+
 size_t depth_sort_temp_bytes(int P) {
   size_t bytes = 0;
-  (void)rocprim::radix_sort_pairs(nullptr, bytes, (const uint32_t*)nullptr, (uint32_t*)nullptr,
+  (void)rocprim::radix_sort_pairs<DepthSortConfig>(nullptr, bytes, (const uint32_t*)nullptr, (uint32_t*)nullptr,
                                   rocprim::counting_iterator<uint32_t>(0), (uint32_t*)nullptr, (size_t)P, 0, 32);
   return bytes;
 }
@@ -372,7 +377,7 @@ extern "C" int gsr_bin_prepare(int P, const uint32_t* records, const uint32_t* d
   uint32_t* keys_sorted = (uint32_t*)base;
   void* temp = base + keys_bytes;
   size_t temp_bytes = scratch_bytes - keys_bytes;
-  hipError_t e = rocprim::radix_sort_pairs(temp, temp_bytes, depth_keys, keys_sorted,
+  hipError_t e = rocprim::radix_sort_pairs<DepthSortConfig>(temp, temp_bytes, depth_keys, keys_sorted,
                                            rocprim::counting_iterator<uint32_t>(0), order, (size_t)P, 0, 32, st);
   if (e != hipSuccess) return gsr::fail(GSR_E_LAUNCH, "bin_prepare: depth sort: %s", hipGetErrorString(e));
   temp_bytes = scratch_bytes - keys_bytes;
