@@ -71,6 +71,8 @@ def main():
     ap.add_argument("--warmup", type=int, default=5)
     ap.add_argument("--workload", default="c3", choices=sorted(WORKLOADS))
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--unfused", action="store_true",
+                    help="apply the model's activations with PyTorch ops, as the reference does, instead of in-kernel")
     args = ap.parse_args()
 
     world = int(os.environ.get("WORLD_SIZE", "1"))
@@ -100,7 +102,7 @@ def main():
     cam = orbit_camera(W, H, angle_deg=45.0 * rank, device=dev)
     bg = torch.zeros(3, device=dev)                                   # train.py:41
     gt = torch.rand(3, H, W, generator=torch.Generator().manual_seed(1)).to(dev)
-    pipe = PipelineParams()
+    pipe = PipelineParams(fused_activations=not args.unfused)
     params = [p for p in model.parameters()]
 
     timer = dgr.StageTimer()
@@ -194,7 +196,9 @@ def _instances(dgr, cam, model, bg):
             prefiltered=False, debug=False)
         st = dgr.rasterize_forward(s, model.get_xyz, model.get_opacity, shs=model.get_features,
                                    scales=model.get_scaling, rotations=model.get_rotation)
-        return st.num_rendered
+        n = st.num_rendered
+        del st
+        return n
 
 
 def cpu_baseline(cloud, W, H, deg):

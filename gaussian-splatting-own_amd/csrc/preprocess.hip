@@ -138,10 +138,29 @@ __device__ __forceinline__ void sh_basis(float x, float y, float z, float* b) {
 // Loads the first N = (D+1)^2 coefficients x 3 channels of Gaussian i into
 // sh[3*k + c].  With the reference's (P,16,3) layout each Gaussian is 192 B,
 // 16-byte aligned: 16-byte loads.  Other M: 4-byte loads.
+// When shs_rest is given the coefficients come from the model's two parameter
+// tensors instead: shs = _features_dc (P,1,3), shs_rest = _features_rest
+// (P,n_rest,3) (scene/gaussian_model.py:108-111 concatenates them per call).
+// rest_row points at this Gaussian's row of _features_rest: n_rest*12 bytes, 4-byte aligned
+// only, so it is read with 16-byte loads declared as 4-byte aligned (gfx950 global loads
+// need dword alignment, not natural alignment).
+typedef float float4u __attribute__((ext_vector_type(4), aligned(4)));
 template <int D>
-__device__ __forceinline__ void load_sh(const float* __restrict__ shs, int M, int i, float* sh) {
+__device__ __forceinline__ void load_sh(const float* __restrict__ shs, const float* __restrict__ rest_row, int M,
+                                        int i, float* sh) {
   constexpr int N = (D + 1) * (D + 1);
-  if (M == 16) {
+  if (rest_row) {
+    const float* dc = shs + (size_t)i * 3;
+    sh[0] = dc[0]; sh[1] = dc[1]; sh[2] = dc[2];
+    constexpr int R = 3 * N - 3, Q = R / 4;
+#pragma unroll
+    for (int k = 0; k < Q; k++) {
+      const float4u v = *reinterpret_cast<const float4u*>(rest_row + 4 * k);
+      sh[3 + 4 * k] = v.x; sh[4 + 4 * k] = v.y; sh[5 + 4 * k] = v.z; sh[6 + 4 * k] = v.w;
+    }
+#pragma unroll
+    for (int k = 4 * Q; k < R; k++) sh[3 + k] = rest_row[k];
+  } else if (M == 16) {
     const float4* p = reinterpret_cast<const float4*>(shs) + (size_t)i * 12;
     constexpr int Q = (3 * N + 3) / 4;
     float4 v[Q];
@@ -159,7 +178,25 @@ __device__ __forceinline__ void load_sh(const float* __restrict__ shs, int M, in
   }
 }
 
+// Raw mode: a block's kBlock rows of a (P, n_rest, 3) tensor are contiguous in memory
+// (n_rest*12 bytes each, 4-byte aligned only).  Each lane fills row threadIdx.x of an LDS
+// tile, which then goes to HBM with fully coalesced dword stores.
+__device__ __forceinline__ void tile_store_rows(float* __restrict__ dst, int P, int R, const float* tile) {
+  __syncthreads();
+  const size_t base = (size_t)blockIdx.x * kBlock * R;
+  const int rows = min(kBlock, P - (int)blockIdx.x * kBlock);
+  for (int e = threadIdx.x; e < rows * R; e += kBlock) dst[base + e] = tile[e];
+}
+
+// Activations of the model's raw parameters (scene/gaussian_model.py:33-41,95-118):
+// scale = exp(raw), opacity = sigmoid(raw), rotation = raw / max(|raw|, 1e-12).
+__device__ __forceinline__ float sigmoidf(float x) { return 1.0f / (1.0f + expf(-x)); }
+__device__ __forceinline__ float quat_norm(const float* q) {
+  return fmaxf(sqrtf(q[0] * q[0] + q[1] * q[1] + q[2] * q[2] + q[3] * q[3]), 1e-12f);
+}
+
 struct FwdArgs {
+  int raw, n_rest; const float* shs_rest;
   int P, M, W, H;
   const float* means3D; const float* scales; const float* rotations; const float* opacities;
   const float* shs; const float* colors_precomp; const float* cov3D_precomp;
@@ -194,9 +231,14 @@ __global__ void __launch_bounds__(kBlock) preprocess_fwd_kernel(FwdArgs a) {
 #pragma unroll
       for (int k = 0; k < 6; k++) c6[k] = a.cov3D_precomp[6 * (size_t)i + k];
     } else {
-      const float s[3] = {a.scales[3 * i], a.scales[3 * i + 1], a.scales[3 * i + 2]};
+      float s[3] = {a.scales[3 * i], a.scales[3 * i + 1], a.scales[3 * i + 2]};
       const float4 qv = reinterpret_cast<const float4*>(a.rotations)[i];
-      const float q[4] = {qv.x, qv.y, qv.z, qv.w};
+      float q[4] = {qv.x, qv.y, qv.z, qv.w};
+      if (a.raw) {
+        s[0] = expf(s[0]); s[1] = expf(s[1]); s[2] = expf(s[2]);
+        const float n = quat_norm(q);
+        q[0] = q[0] / n; q[1] = q[1] / n; q[2] = q[2] / n; q[3] = q[3] / n;
+      }
       cov3d_from_scale_rot(s, a.scale_modifier, q, c6);
     }
     Ewa e;
@@ -220,7 +262,7 @@ __global__ void __launch_bounds__(kBlock) preprocess_fwd_kernel(FwdArgs a) {
       x1 = (int)fminf((float)gx, fmaxf(0.0f, (pxs + rr + (float)(GSR_TILE_X - 1)) / (float)GSR_TILE_X));
       y1 = (int)fminf((float)gy, fmaxf(0.0f, (pys + rr + (float)(GSR_TILE_Y - 1)) / (float)GSR_TILE_Y));
       vis = (x1 - x0) * (y1 - y0) > 0;
-      opacity = a.opacities[i];
+      opacity = a.raw ? sigmoidf(a.opacities[i]) : a.opacities[i];
       // Half extents of the region where alpha can reach 1/255: the ellipse
       // d^T conic d <= 2 ln(255 o) spans sqrt(2 ln(255 o) * cov_xx) in x.
       // Widened a little so that rounding can never make it exclusive.
@@ -253,7 +295,7 @@ __global__ void __launch_bounds__(kBlock) preprocess_fwd_kernel(FwdArgs a) {
     constexpr int N = (D + 1) * (D + 1);
     float bas[N], sh[3 * N], col[3];
     sh_basis<D>(dx, dy, dz, bas);
-    load_sh<D>(a.shs, a.M, i, sh);
+    load_sh<D>(a.shs, a.shs_rest ? a.shs_rest + (size_t)i * (a.n_rest * 3) : nullptr, a.M, i, sh);
 #pragma unroll
     for (int ch = 0; ch < 3; ch++) {
       float acc = bas[0] * sh[ch];
@@ -287,6 +329,7 @@ __global__ void __launch_bounds__(kBlock) mark_visible_kernel(int P, const float
 }
 
 struct BwdArgs {
+  int raw, n_rest; const float* shs_rest; const float* opacity_raw; float* dL_dshs_rest;
   int P, M, W, H;
   const float* means3D; const float* scales; const float* rotations; const float* shs;
   const float* cov3D_precomp; const float* view; const float* proj; const float* campos;
@@ -305,11 +348,13 @@ __device__ __forceinline__ void store_f4(float* dst, const float* v) {
 }
 
 template <int D>
-__global__ void __launch_bounds__(kBlock) preprocess_bwd_kernel(BwdArgs a) {
+__global__ void __launch_bounds__(kBlock, 4) preprocess_bwd_kernel(BwdArgs a) {
+  extern __shared__ float rest_tile[];   // raw mode only: the block's rows of the _features_rest gradient
   const int i = blockIdx.x * kBlock + threadIdx.x;
-  if (i >= a.P) return;
-  const uint4 r3 = reinterpret_cast<const uint4*>(a.records)[(size_t)i * 4 + 3];
-  const bool vis = (int)r3.z > 0;
+  const bool valid = i < a.P;
+  uint4 r3 = make_uint4(0u, 0u, 0u, 0u);
+  if (valid) r3 = reinterpret_cast<const uint4*>(a.records)[(size_t)i * 4 + 3];
+  const bool vis = valid && (int)r3.z > 0;
   const float4* gsp = reinterpret_cast<const float4*>(a.dL_dsplat) + (size_t)i * (GSR_GRAD_WORDS / 4);
   float4 g0 = make_float4(0, 0, 0, 0), g1 = g0, g2 = g0;
   if (vis) { g0 = gsp[0]; g1 = gsp[1]; g2 = gsp[2]; }
@@ -328,7 +373,7 @@ __global__ void __launch_bounds__(kBlock) preprocess_bwd_kernel(BwdArgs a) {
     const float* PV = a.proj;
     const Vec3 pv = xform43(V, px3, py3, pz3);
     float c6[6];
-    float s[3] = {0.f, 0.f, 0.f}, q[4] = {1.f, 0.f, 0.f, 0.f};
+    float s[3] = {0.f, 0.f, 0.f}, q[4] = {1.f, 0.f, 0.f, 0.f}, qn = 1.0f;
     if (a.cov3D_precomp) {
 #pragma unroll
       for (int k = 0; k < 6; k++) c6[k] = a.cov3D_precomp[6 * (size_t)i + k];
@@ -336,6 +381,11 @@ __global__ void __launch_bounds__(kBlock) preprocess_bwd_kernel(BwdArgs a) {
       s[0] = a.scales[3 * i]; s[1] = a.scales[3 * i + 1]; s[2] = a.scales[3 * i + 2];
       const float4 qv = reinterpret_cast<const float4*>(a.rotations)[i];
       q[0] = qv.x; q[1] = qv.y; q[2] = qv.z; q[3] = qv.w;
+      if (a.raw) {
+        s[0] = expf(s[0]); s[1] = expf(s[1]); s[2] = expf(s[2]);
+        qn = quat_norm(q);
+        q[0] = q[0] / qn; q[1] = q[1] / qn; q[2] = q[2] / qn; q[3] = q[3] / qn;
+      }
       cov3d_from_scale_rot(s, a.scale_modifier, q, c6);
     }
     Ewa e;
@@ -403,7 +453,7 @@ __global__ void __launch_bounds__(kBlock) preprocess_bwd_kernel(BwdArgs a) {
       const float x = dirx / len, y = diry / len, z = dirz / len;
       float bas[N], sh[3 * N];
       sh_basis<D>(x, y, z, bas);
-      load_sh<D>(a.shs, a.M, i, sh);
+      load_sh<D>(a.shs, a.shs_rest ? a.shs_rest + (size_t)i * (a.n_rest * 3) : nullptr, a.M, i, sh);
       const float dRGB[3] = {(r3.w & 1u) ? 0.f : g1.z, (r3.w & 2u) ? 0.f : g1.w, (r3.w & 4u) ? 0.f : g2.x};
 #pragma unroll
       for (int k = 0; k < N; k++) {
@@ -470,17 +520,43 @@ __global__ void __launch_bounds__(kBlock) preprocess_bwd_kernel(BwdArgs a) {
       drot[1] = 2.0f * (y * dR[1] + z * dR[2] + y * dR[3] - 2.0f * x * dR[4] - r * dR[5] + z * dR[6] + r * dR[7] - 2.0f * x * dR[8]);
       drot[2] = 2.0f * (-2.0f * y * dR[0] + x * dR[1] + r * dR[2] + x * dR[3] + z * dR[5] - r * dR[6] + z * dR[7] - 2.0f * y * dR[8]);
       drot[3] = 2.0f * (-2.0f * z * dR[0] - r * dR[1] + x * dR[2] + r * dR[3] - 2.0f * z * dR[4] + y * dR[5] + x * dR[6] + y * dR[7]);
+      if (a.raw) {
+        // back through exp and normalize: d/draw = dscale * scale; (g - q (q.g)) / |raw|
+        dscale[0] *= s[0]; dscale[1] *= s[1]; dscale[2] *= s[2];
+        const float qg = q[0] * drot[0] + q[1] * drot[1] + q[2] * drot[2] + q[3] * drot[3];
+#pragma unroll
+        for (int k = 0; k < 4; k++) drot[k] = (drot[k] - q[k] * qg) / qn;
+      }
     }
   }
+  float dopac = g1.y;
+  if (a.raw && vis) {
+    const float o = sigmoidf(a.opacity_raw[i]);
+    dopac = dopac * (o * (1.0f - o));
+  }
 
+  if (a.dL_dshs_rest) {
+    // each lane puts its row into the LDS tile, then the block stores the tile fully coalesced
+    const int R = a.n_rest * 3;
+    float* row = rest_tile + threadIdx.x * R;
+#pragma unroll
+    for (int k = 3; k < 48; k++)
+      if (k - 3 < R) row[k - 3] = dsh[k];
+    tile_store_rows(a.dL_dshs_rest, a.P, R, rest_tile);
+    if (valid) {
+      float* dc = a.dL_dshs + (size_t)i * 3;
+      dc[0] = dsh[0]; dc[1] = dsh[1]; dc[2] = dsh[2];
+    }
+  }
+  if (!valid) return;
   a.dL_dmeans3D[3 * (size_t)i] = dmean[0];
   a.dL_dmeans3D[3 * (size_t)i + 1] = dmean[1];
   a.dL_dmeans3D[3 * (size_t)i + 2] = dmean[2];
   a.dL_dmeans2D[3 * (size_t)i] = g0.x;
   a.dL_dmeans2D[3 * (size_t)i + 1] = g0.y;
   a.dL_dmeans2D[3 * (size_t)i + 2] = 0.f;
-  a.dL_dopacities[i] = g1.y;
-  if (a.dL_dshs) {
+  a.dL_dopacities[i] = dopac;
+  if (!a.dL_dshs_rest && a.dL_dshs) {
     float* dst = a.dL_dshs + (size_t)i * a.M * 3;
     if (a.M == 16) {
       store_f4<48>(dst, dsh);
@@ -528,7 +604,7 @@ extern "C" int gsr_preprocess_fwd(int P, int D, int M, const float* means3D, con
   GSR_REQUIRE(D >= 0 && D <= GSR_MAX_SH_DEGREE, "preprocess_fwd: SH degree %d unsupported (0..3)", D);
   GSR_REQUIRE(!shs || M >= (D + 1) * (D + 1), "preprocess_fwd: M=%d too small for degree %d", M, D);
   GSR_REQUIRE(W <= 16 * 65535 && H <= 16 * 65535, "preprocess_fwd: image too large");
-  FwdArgs a{P, M, W, H, means3D, scales, rotations, opacities, shs, colors_precomp, cov3D_precomp,
+  FwdArgs a{0, 0, nullptr, P, M, W, H, means3D, scales, rotations, opacities, shs, colors_precomp, cov3D_precomp,
             viewmatrix, projmatrix, campos, scale_modifier, tanfovx, tanfovy,
             records, radii, tiles_touched, depth_keys};
   hipStream_t st = (hipStream_t)stream;
@@ -574,7 +650,7 @@ extern "C" int gsr_preprocess_bwd(int P, int D, int M, const float* means3D, con
               "preprocess_bwd: scales/rotations and their gradients go together");
   GSR_REQUIRE(D >= 0 && D <= GSR_MAX_SH_DEGREE, "preprocess_bwd: SH degree %d unsupported", D);
   GSR_REQUIRE(!shs || (M >= (D + 1) * (D + 1) && M <= 16), "preprocess_bwd: M=%d unsupported for degree %d", M, D);
-  BwdArgs a{P, M, W, H, means3D, scales, rotations, shs, cov3D_precomp, viewmatrix, projmatrix, campos,
+  BwdArgs a{0, 0, nullptr, nullptr, nullptr, P, M, W, H, means3D, scales, rotations, shs, cov3D_precomp, viewmatrix, projmatrix, campos,
             scale_modifier, tanfovx, tanfovy, records, dL_dsplat, dL_dmeans3D, dL_dmeans2D, dL_dopacities,
             dL_dshs, dL_dcolors, dL_dscales, dL_drotations, dL_dcov3D};
   hipStream_t st = (hipStream_t)stream;
@@ -587,4 +663,75 @@ extern "C" int gsr_preprocess_bwd(int P, int D, int M, const float* means3D, con
     default: hipLaunchKernelGGL(preprocess_bwd_kernel<3>, grid, block, 0, st, a); break;
   }
   return gsr::check_launch("preprocess_bwd");
+}
+
+// ---------------------------------------------------------------------------
+// Raw-parameter variants: the model's exp / sigmoid / normalize / concatenate
+// (scene/gaussian_model.py:95-118, five elementwise kernels and a 192 MB copy
+// per call at 1M Gaussians, and as many again in backward) folded into the
+// per-Gaussian kernels.  Same kernels, `raw` switches the loads and the chain rule.
+// ---------------------------------------------------------------------------
+extern "C" int gsr_preprocess_fwd_raw(int P, int D, int n_rest, const float* xyz, const float* scaling_raw,
+                                      float scale_modifier, const float* rotation_raw, const float* opacity_raw,
+                                      const float* features_dc, const float* features_rest,
+                                      const float* viewmatrix, const float* projmatrix, const float* campos, int W,
+                                      int H, float tanfovx, float tanfovy, uint32_t* records, int32_t* radii,
+                                      uint32_t* tiles_touched, uint32_t* depth_keys, void* stream) {
+  GSR_REQUIRE(P >= 0 && W > 0 && H > 0, "preprocess_fwd_raw: bad sizes P=%d W=%d H=%d", P, W, H);
+  if (P == 0) return GSR_OK;
+  GSR_REQUIRE(xyz && scaling_raw && rotation_raw && opacity_raw && features_dc && viewmatrix && projmatrix && campos,
+              "preprocess_fwd_raw: null input");
+  GSR_REQUIRE(records && radii && tiles_touched && depth_keys, "preprocess_fwd_raw: null output");
+  GSR_REQUIRE(D >= 0 && D <= GSR_MAX_SH_DEGREE, "preprocess_fwd_raw: SH degree %d unsupported (0..3)", D);
+  GSR_REQUIRE(n_rest >= (D + 1) * (D + 1) - 1 && n_rest <= 15 && (n_rest == 0 || features_rest),
+              "preprocess_fwd_raw: n_rest=%d does not hold degree %d", n_rest, D);
+  GSR_REQUIRE(W <= 16 * 65535 && H <= 16 * 65535, "preprocess_fwd_raw: image too large");
+  // with D == 0 and no rest tensor the dc tensor alone is a (P,1,3) shs tensor
+  const bool split = n_rest > 0;
+  FwdArgs a{1, n_rest, split ? features_rest : nullptr, P, 1 + n_rest, W, H, xyz, scaling_raw, rotation_raw,
+            opacity_raw, features_dc, nullptr, nullptr, viewmatrix, projmatrix, campos, scale_modifier, tanfovx,
+            tanfovy, records, radii, tiles_touched, depth_keys};
+  hipStream_t st = (hipStream_t)stream;
+  dim3 grid(gsr::div_up(P, kBlock)), block(kBlock);
+  switch (D) {
+    case 0: hipLaunchKernelGGL(preprocess_fwd_kernel<0>, grid, block, 0, st, a); break;
+    case 1: hipLaunchKernelGGL(preprocess_fwd_kernel<1>, grid, block, 0, st, a); break;
+    case 2: hipLaunchKernelGGL(preprocess_fwd_kernel<2>, grid, block, 0, st, a); break;
+    default: hipLaunchKernelGGL(preprocess_fwd_kernel<3>, grid, block, 0, st, a); break;
+  }
+  return gsr::check_launch("preprocess_fwd_raw");
+}
+
+extern "C" int gsr_preprocess_bwd_raw(int P, int D, int n_rest, const float* xyz, const float* scaling_raw,
+                                      float scale_modifier, const float* rotation_raw, const float* opacity_raw,
+                                      const float* features_dc, const float* features_rest,
+                                      const float* viewmatrix, const float* projmatrix, const float* campos, int W,
+                                      int H, float tanfovx, float tanfovy, const uint32_t* records,
+                                      const float* dL_dsplat, float* dL_dxyz, float* dL_dmeans2D,
+                                      float* dL_dopacity_raw, float* dL_dfeatures_dc, float* dL_dfeatures_rest,
+                                      float* dL_dscaling_raw, float* dL_drotation_raw, void* stream) {
+  GSR_REQUIRE(P >= 0 && W > 0 && H > 0, "preprocess_bwd_raw: bad sizes");
+  if (P == 0) return GSR_OK;
+  GSR_REQUIRE(xyz && scaling_raw && rotation_raw && opacity_raw && features_dc && viewmatrix && projmatrix && campos &&
+                  records && dL_dsplat, "preprocess_bwd_raw: null input");
+  GSR_REQUIRE(dL_dxyz && dL_dmeans2D && dL_dopacity_raw && dL_dfeatures_dc && dL_dscaling_raw && dL_drotation_raw,
+              "preprocess_bwd_raw: null output");
+  GSR_REQUIRE(D >= 0 && D <= GSR_MAX_SH_DEGREE, "preprocess_bwd_raw: SH degree %d unsupported", D);
+  GSR_REQUIRE(n_rest >= (D + 1) * (D + 1) - 1 && n_rest <= 15 && (n_rest == 0 || (features_rest && dL_dfeatures_rest)),
+              "preprocess_bwd_raw: n_rest=%d does not hold degree %d", n_rest, D);
+  const bool split = n_rest > 0;
+  BwdArgs a{1, n_rest, split ? features_rest : nullptr, opacity_raw, split ? dL_dfeatures_rest : nullptr,
+            P, 1 + n_rest, W, H, xyz, scaling_raw, rotation_raw, features_dc, nullptr, viewmatrix, projmatrix, campos,
+            scale_modifier, tanfovx, tanfovy, records, dL_dsplat, dL_dxyz, dL_dmeans2D, dL_dopacity_raw,
+            dL_dfeatures_dc, nullptr, dL_dscaling_raw, dL_drotation_raw, nullptr};
+  hipStream_t st = (hipStream_t)stream;
+  dim3 grid(gsr::div_up(P, kBlock)), block(kBlock);
+  const size_t lds = split ? (size_t)kBlock * n_rest * 3 * sizeof(float) : 0;
+  switch (D) {
+    case 0: hipLaunchKernelGGL(preprocess_bwd_kernel<0>, grid, block, lds, st, a); break;
+    case 1: hipLaunchKernelGGL(preprocess_bwd_kernel<1>, grid, block, lds, st, a); break;
+    case 2: hipLaunchKernelGGL(preprocess_bwd_kernel<2>, grid, block, lds, st, a); break;
+    default: hipLaunchKernelGGL(preprocess_bwd_kernel<3>, grid, block, lds, st, a); break;
+  }
+  return gsr::check_launch("preprocess_bwd_raw");
 }

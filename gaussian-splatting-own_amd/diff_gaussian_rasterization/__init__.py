@@ -55,6 +55,10 @@ def _load():
     lib.gsr_blend_bwd.argtypes = [ci, ci, vp, vp, vp, vp, vp, vp, vp, vp, vp]
     lib.gsr_preprocess_bwd.argtypes = [ci, ci, ci, vp, vp, cf, vp, vp, vp, vp, vp, vp, ci, ci, cf, cf, vp, vp,
                                        vp, vp, vp, vp, vp, vp, vp, vp, vp]
+    lib.gsr_preprocess_fwd_raw.argtypes = [ci, ci, ci, vp, vp, cf, vp, vp, vp, vp, vp, vp, vp, ci, ci, cf, cf,
+                                           vp, vp, vp, vp, vp]
+    lib.gsr_preprocess_bwd_raw.argtypes = [ci, ci, ci, vp, vp, cf, vp, vp, vp, vp, vp, vp, vp, ci, ci, cf, cf,
+                                           vp, vp, vp, vp, vp, vp, vp, vp, vp, vp]
     return lib
 
 
@@ -177,9 +181,13 @@ class ForwardState:
 
 
 def rasterize_forward(s: GaussianRasterizationSettings, means3D, opacities, shs=None, colors_precomp=None,
-                      scales=None, rotations=None, cov3D_precomp=None, keep_tile_ids: bool = False) -> ForwardState:
+                      scales=None, rotations=None, cov3D_precomp=None, keep_tile_ids: bool = False,
+                      raw: Optional[dict] = None) -> ForwardState:
     """preprocess -> bin -> blend on the current stream; one host read-back
-    (the instance count) in the middle, as in the module it replaces."""
+    (the instance count) in the middle, as in the module it replaces.
+    With ``raw`` (features_dc, features_rest, scaling, rotation, opacity: the model's raw
+    parameters) the activations run inside the preprocess kernel and the activated
+    arguments are ignored."""
     means3D = _f32(means3D, "means3D")
     dev = means3D.device if means3D is not None else s.bg.device
     st = ForwardState()
@@ -206,12 +214,21 @@ def rasterize_forward(s: GaussianRasterizationSettings, means3D, opacities, shs=
     st.n_contrib = torch.empty((H, W), **u32)
     st.tile_ids_sorted = None
     N = NC = 0
-    if P > 0:
+    if P > 0 and raw is not None:
+        r = {k: _f32(v, k) for k, v in raw.items()}
+        n_rest = 0 if r["features_rest"] is None else r["features_rest"].shape[1]
+        st.M = 1 + n_rest
+        _run("preprocess_fwd", _lib.gsr_preprocess_fwd_raw, P, st.D, n_rest, _ptr(means3D), _ptr(r["scaling"]),
+             float(s.scale_modifier), _ptr(r["rotation"]), _ptr(r["opacity"]), _ptr(r["features_dc"]),
+             _ptr(r["features_rest"]), _ptr(st.view), _ptr(st.proj), _ptr(st.campos), W, H, float(s.tanfovx),
+             float(s.tanfovy), _ptr(st.records), _ptr(st.radii), _ptr(st.tiles_touched), _ptr(st.depth_keys), stream)
+    elif P > 0:
         _run("preprocess_fwd", _lib.gsr_preprocess_fwd, P, st.D, st.M, _ptr(means3D), _ptr(scales),
              float(s.scale_modifier), _ptr(rotations), _ptr(opacities), _ptr(shs), _ptr(colors_precomp),
              _ptr(cov3D_precomp), _ptr(st.view), _ptr(st.proj), _ptr(st.campos), W, H, float(s.tanfovx),
              float(s.tanfovy), int(bool(s.prefiltered)), _ptr(st.records), _ptr(st.radii), _ptr(st.tiles_touched),
              _ptr(st.depth_keys), stream)
+    if P > 0:
         nb = _lib.gsr_bin_prepare_bytes(P)
         scratch = torch.empty((nb,), dtype=torch.uint8, device=dev)
         totals = torch.empty((2,), **u32)
@@ -273,6 +290,69 @@ def rasterize_backward(s: GaussianRasterizationSettings, st: ForwardState, grad_
             _ptr(g["opacities"]), _ptr(g["shs"]), _ptr(g["colors_precomp"]), _ptr(g["scales"]), _ptr(g["rotations"]),
             _ptr(g["cov3D_precomp"]), _stream())
     return g
+
+
+def rasterize_backward_raw(s: GaussianRasterizationSettings, st: ForwardState, grad_color, xyz, raw: dict,
+                           dsplat=None):
+    """Gradients w.r.t. the model's raw parameters (activations' chain rule in-kernel)."""
+    xyz = _f32(xyz, "xyz")
+    r = {k: _f32(v, k) for k, v in raw.items()}
+    dev = grad_color.device
+    P = st.P
+    if dsplat is None:
+        dsplat = blend_backward(st, grad_color)
+    f = dict(dtype=torch.float32, device=dev)
+    n_rest = 0 if r["features_rest"] is None else r["features_rest"].shape[1]
+    g = dict(xyz=torch.empty((P, 3), **f), means2D=torch.empty((P, 3), **f), opacity=torch.empty((P, 1), **f),
+             features_dc=torch.empty((P, 1, 3), **f),
+             features_rest=torch.empty((P, n_rest, 3), **f) if n_rest else None,
+             scaling=torch.empty((P, 3), **f), rotation=torch.empty((P, 4), **f))
+    if P > 0:
+        _run("preprocess_bwd", _lib.gsr_preprocess_bwd_raw, P, st.D, n_rest, _ptr(xyz), _ptr(r["scaling"]),
+             float(s.scale_modifier), _ptr(r["rotation"]), _ptr(r["opacity"]), _ptr(r["features_dc"]),
+             _ptr(r["features_rest"]), _ptr(st.view), _ptr(st.proj), _ptr(st.campos), st.W, st.H, float(s.tanfovx),
+             float(s.tanfovy), _ptr(st.records), _ptr(dsplat), _ptr(g["xyz"]), _ptr(g["means2D"]), _ptr(g["opacity"]),
+             _ptr(g["features_dc"]), _ptr(g["features_rest"]), _ptr(g["scaling"]), _ptr(g["rotation"]), _stream())
+    return g
+
+
+class _RasterizeGaussiansRaw(torch.autograd.Function):
+    """Same operator on the model's raw parameters: exp / sigmoid / normalize / dc|rest
+    concatenation and their backward run inside the per-Gaussian kernels."""
+
+    @staticmethod
+    def forward(ctx, xyz, means2D, features_dc, features_rest, opacity_raw, scaling_raw, rotation_raw,
+                raster_settings):
+        raw = dict(features_dc=features_dc, features_rest=_empty_to_none(features_rest), scaling=scaling_raw,
+                   rotation=rotation_raw, opacity=opacity_raw)
+        st = rasterize_forward(raster_settings, xyz, None, raw=raw)
+        if raster_settings.debug:
+            torch.cuda.synchronize()
+        ctx.raster_settings = raster_settings
+        ctx.state = st
+        ctx.save_for_backward(xyz, features_dc, features_rest, opacity_raw, scaling_raw, rotation_raw)
+        ctx.mark_non_differentiable(st.radii)
+        return st.color, st.radii
+
+    @staticmethod
+    def backward(ctx, grad_out_color, _grad_radii):
+        xyz, features_dc, features_rest, opacity_raw, scaling_raw, rotation_raw = ctx.saved_tensors
+        raw = dict(features_dc=features_dc, features_rest=_empty_to_none(features_rest), scaling=scaling_raw,
+                   rotation=rotation_raw, opacity=opacity_raw)
+        g = rasterize_backward_raw(ctx.raster_settings, ctx.state, grad_out_color, xyz, raw)
+        if ctx.raster_settings.debug:
+            torch.cuda.synchronize()
+        return (g["xyz"], g["means2D"], g["features_dc"], g["features_rest"], g["opacity"], g["scaling"],
+                g["rotation"], None)
+
+
+def rasterize_gaussians_raw(xyz, means2D, features_dc, features_rest, opacity_raw, scaling_raw, rotation_raw,
+                            raster_settings):
+    """(color, radii) from raw model parameters; an extension, not part of the reference's API."""
+    if features_rest is None:
+        features_rest = torch.Tensor([])
+    return _RasterizeGaussiansRaw.apply(xyz, means2D, features_dc, features_rest, opacity_raw, scaling_raw,
+                                        rotation_raw, raster_settings)
 
 
 def _empty_to_none(t):

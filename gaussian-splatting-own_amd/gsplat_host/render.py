@@ -13,7 +13,8 @@ from dataclasses import dataclass
 
 import torch
 
-from diff_gaussian_rasterization import GaussianRasterizationSettings, GaussianRasterizer
+from diff_gaussian_rasterization import (GaussianRasterizationSettings, GaussianRasterizer,
+                                          rasterize_gaussians_raw)
 
 from .sh import eval_sh
 
@@ -24,6 +25,9 @@ class PipelineParams:
     convert_SHs_python: bool = False
     compute_cov3D_python: bool = False
     debug: bool = False
+    # extension (not in the reference): hand the model's raw parameters to the rasterizer and let
+    # it apply exp / sigmoid / normalize / dc|rest concatenation, and their backward, in-kernel
+    fused_activations: bool = False
 
 
 def render(viewpoint_camera, pc, pipe: PipelineParams, bg_color: torch.Tensor, scaling_modifier: float = 1.0,
@@ -42,6 +46,12 @@ def render(viewpoint_camera, pc, pipe: PipelineParams, bg_color: torch.Tensor, s
         bg=bg_color, scale_modifier=scaling_modifier, viewmatrix=viewpoint_camera.world_view_transform,
         projmatrix=viewpoint_camera.full_proj_transform, sh_degree=pc.active_sh_degree,
         campos=viewpoint_camera.camera_center, prefiltered=False, debug=pipe.debug)
+    if (pipe.fused_activations and override_color is None and not pipe.convert_SHs_python
+            and not pipe.compute_cov3D_python and hasattr(pc, "_features_rest")):
+        image, radii = rasterize_gaussians_raw(xyz, screenspace_points, pc._features_dc, pc._features_rest,
+                                               pc._opacity, pc._scaling, pc._rotation, settings)
+        return {"render": image, "viewspace_points": screenspace_points, "visibility_filter": radii > 0,
+                "radii": radii}
     rasterizer = GaussianRasterizer(raster_settings=settings)
 
     scales = rotations = cov3D_precomp = None

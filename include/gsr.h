@@ -172,6 +172,31 @@ int gsr_preprocess_bwd(int P, int D, int M, const float* means3D, const float* s
                        float* dL_dshs, float* dL_dcolors, float* dL_dscales,
                        float* dL_drotations, float* dL_dcov3D, void* stream);
 
+/* ---- Raw-parameter variants of the per-Gaussian stages -----------------------
+ * The reference applies its activations in separate PyTorch kernels on every
+ * call (scene/gaussian_model.py:95-118: exp, sigmoid, normalize, and a
+ * concatenation of _features_dc (P,1,3) with _features_rest (P,n_rest,3)) and
+ * differentiates through them again in backward.  These two entry points take
+ * the RAW parameters and fold the activations, and their chain rule, into the
+ * kernels; everything downstream (binning, blending) is unchanged.
+ * n_rest = coefficients in features_rest (15 for degree 3; 0 = no rest tensor).
+ * Gradient outputs are with respect to the raw parameters. */
+int gsr_preprocess_fwd_raw(int P, int D, int n_rest, const float* xyz, const float* scaling_raw,
+                           float scale_modifier, const float* rotation_raw, const float* opacity_raw,
+                           const float* features_dc, const float* features_rest,
+                           const float* viewmatrix, const float* projmatrix, const float* campos,
+                           int W, int H, float tanfovx, float tanfovy, uint32_t* records,
+                           int32_t* radii, uint32_t* tiles_touched, uint32_t* depth_keys,
+                           void* stream);
+int gsr_preprocess_bwd_raw(int P, int D, int n_rest, const float* xyz, const float* scaling_raw,
+                           float scale_modifier, const float* rotation_raw, const float* opacity_raw,
+                           const float* features_dc, const float* features_rest,
+                           const float* viewmatrix, const float* projmatrix, const float* campos,
+                           int W, int H, float tanfovx, float tanfovy, const uint32_t* records,
+                           const float* dL_dsplat, float* dL_dxyz, float* dL_dmeans2D,
+                           float* dL_dopacity_raw, float* dL_dfeatures_dc, float* dL_dfeatures_rest,
+                           float* dL_dscaling_raw, float* dL_drotation_raw, void* stream);
+
 /* ---- Photometric loss ------------------------------------------------------
  * The step that follows the rasterizer in every training iteration
  * (train.py:90-92): loss = (1 - lambda) * mean|img - gt| + lambda * (1 - SSIM),
