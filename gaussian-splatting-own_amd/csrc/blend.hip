@@ -16,7 +16,6 @@ namespace {
 
 constexpr int kBatch = 256;
 constexpr float kLog2e = 1.4426950408889634f;
-constexpr float kLn2 = 0.6931471805599453f;
 
 struct Pixel {
   int x, y;       // pixel coordinates
@@ -231,8 +230,6 @@ __global__ void __launch_bounds__(256) blend_bwd_kernel(int W, int H, const uint
   float dp0 = 0.f, dp1 = 0.f, dp2 = 0.f;
   if (px.inside) { dp0 = dL_dpix[pix]; dp1 = dL_dpix[plane + pix]; dp2 = dL_dpix[2 * plane + pix]; }
   const float bg_dot = bg[0] * dp0 + bg[1] * dp1 + bg[2] * dp2;
-  const float ddelx_dx = 0.5f * (float)W, ddely_dy = 0.5f * (float)H;
-
   // the tile starts at the deepest position any of its pixels used
   int wl = last;
 #pragma unroll
@@ -243,7 +240,9 @@ __global__ void __launch_bounds__(256) blend_bwd_kernel(int W, int H, const uint
   const int tile_last = max(max(s_last[0], s_last[1]), max(s_last[2], s_last[3]));
   if (tile_last == 0 || total == 0) return;
 
-  float T = Tf, acc0 = 0.f, acc1 = 0.f, acc2 = 0.f, lc0 = 0.f, lc1 = 0.f, lc2 = 0.f, last_alpha = 0.f;
+  // acc = colour composited behind the current splat (everything already visited in this
+  // back-to-front walk), per channel.
+  float T = Tf, acc0 = 0.f, acc1 = 0.f, acc2 = 0.f;
 
   for (int b = (tile_last - 1) / kBatch; b >= 0; b--) {
     __syncthreads();
@@ -278,54 +277,45 @@ __global__ void __launch_bounds__(256) blend_bwd_kernel(int W, int H, const uint
         const int pos = b * kBatch + j;   // 0-based position in the tile list
         const float4 ga = s_geo[j];
         const float4 co = s_col[j];
+        const float blue = s_blue[j];
         const float dx = ga.x - pxf, dy = ga.y - pyf;
-        const float p = gauss_exponent(ga.z, ga.w, co.x, dx, dy);   // identical to the forward's
-        float g_mx = 0.f, g_my = 0.f, g_a = 0.f, g_b = 0.f, g_c = 0.f, g_o = 0.f, g_r = 0.f, g_g = 0.f, g_bl = 0.f;
-        bool hit = false;
-        if (pos < last && p <= 0.0f) {
-          const float G = __builtin_amdgcn_exp2f(p);
-          const float alpha = fminf(GSR_ALPHA_MAX, co.y * G);
-          if (alpha >= GSR_ALPHA_MIN) {
-            hit = true;
-            const float inv = __builtin_amdgcn_rcpf(1.0f - alpha);
-            T = T * inv;
-            const float dch = alpha * T;
-            const float blue = s_blue[j];
-            acc0 = last_alpha * lc0 + (1.0f - last_alpha) * acc0;
-            acc1 = last_alpha * lc1 + (1.0f - last_alpha) * acc1;
-            acc2 = last_alpha * lc2 + (1.0f - last_alpha) * acc2;
-            lc0 = co.z; lc1 = co.w; lc2 = blue;
-            float dL_dalpha = (co.z - acc0) * dp0 + (co.w - acc1) * dp1 + (blue - acc2) * dp2;
-            g_r = dch * dp0; g_g = dch * dp1; g_bl = dch * dp2;
-            dL_dalpha *= T;
-            last_alpha = alpha;
-            dL_dalpha += (-Tf * inv) * bg_dot;
-            const float dL_dG = co.y * dL_dalpha;
-            const float gdx = G * dx, gdy = G * dy;
-            // -A = 2 la / log2e, -B = lb / log2e, -C = 2 lc / log2e
-            const float dG_ddelx = kLn2 * (2.0f * gdx * ga.z + gdy * ga.w);
-            const float dG_ddely = kLn2 * (2.0f * gdy * co.x + gdx * ga.w);
-            g_mx = dL_dG * dG_ddelx * ddelx_dx;
-            g_my = dL_dG * dG_ddely * ddely_dy;
-            g_a = -0.5f * gdx * dx * dL_dG;
-            g_b = -gdx * dy * dL_dG;
-            g_c = -0.5f * gdy * dy * dL_dG;
-            g_o = G * dL_dalpha;
-          }
-        }
+        // same alpha and same keep / skip decision as the forward, as straight-line code: a pixel
+        // that did not blend this splat gets alpha = 0, which leaves T and acc unchanged below
+        const float p = gauss_exponent(ga.z, ga.w, co.x, dx, dy);
+        const float G = __builtin_amdgcn_exp2f(p);
+        float alpha = fminf(GSR_ALPHA_MAX, co.y * G);
+        alpha = p <= 0.0f ? alpha : 0.0f;
+        alpha = alpha >= GSR_ALPHA_MIN ? alpha : 0.0f;
+        alpha = pos < last ? alpha : 0.0f;
+        const bool hit = alpha > 0.0f;
         if (__ballot(hit) == 0ull) continue;
+
+        const float inv = __builtin_amdgcn_rcpf(1.0f - alpha);     // alpha == 0: exactly 1
+        T = T * inv;                                               // transmittance in front of the splat
+        const float dch = alpha * T;
+        const float d0 = co.z - acc0, d1 = co.w - acc1, d2 = blue - acc2;
+        float dL_dalpha = (d0 * dp0 + d1 * dp1 + d2 * dp2) * T - (Tf * inv) * bg_dot;
+        acc0 = fmaf(alpha, d0, acc0);                              // alpha c + (1 - alpha) acc
+        acc1 = fmaf(alpha, d1, acc1);
+        acc2 = fmaf(alpha, d2, acc2);
+        // u = dL/dG * G.  Everything geometric is a moment of u over the pixels:
+        //   dL/dopacity = sum u / o,  dL/dmean ~ (sum u dx, sum u dy),  dL/dconic ~ (sum u dx^2, ...)
+        // the per-splat factors are applied once per Gaussian by the preprocess backward.
+        float u = (co.y * dL_dalpha) * G;
+        u = hit ? u : 0.0f;
+        const float ux = u * dx, uy = u * dy;
+        float g0 = u, g1 = ux, g2 = uy, g3 = ux * dx, g4 = ux * dy, g5 = uy * dy;
+        float g6 = dch * dp0, g7 = dch * dp1, g8 = dch * dp2;
         // Nine sums over 64 lanes: reduce each within its row of 16 (every lane of a row then
         // holds the nine row sums), let lane k of every row keep sum k, and add the four rows
         // lane-wise.  Lanes 0..8 then issue ONE wave-instruction on nine consecutive dwords of
         // one 64-byte row = one atomic request.
-        g_mx = row_sum(g_mx); g_my = row_sum(g_my);
-        g_a = row_sum(g_a); g_b = row_sum(g_b); g_c = row_sum(g_c);
-        g_o = row_sum(g_o);
-        g_r = row_sum(g_r); g_g = row_sum(g_g); g_bl = row_sum(g_bl);
+        g0 = row_sum(g0); g1 = row_sum(g1); g2 = row_sum(g2); g3 = row_sum(g3); g4 = row_sum(g4);
+        g5 = row_sum(g5); g6 = row_sum(g6); g7 = row_sum(g7); g8 = row_sum(g8);
         const int k = lane & 15;
-        float v = g_mx;
-        v = k == 1 ? g_my : v; v = k == 2 ? g_a : v; v = k == 3 ? g_b : v; v = k == 4 ? g_c : v;
-        v = k == 5 ? g_o : v; v = k == 6 ? g_r : v; v = k == 7 ? g_g : v; v = k == 8 ? g_bl : v;
+        float v = g0;
+        v = k == 1 ? g1 : v; v = k == 2 ? g2 : v; v = k == 3 ? g3 : v; v = k == 4 ? g4 : v;
+        v = k == 5 ? g5 : v; v = k == 6 ? g6 : v; v = k == 7 ? g7 : v; v = k == 8 ? g8 : v;
         v = sum_across_rows(v);
         if (lane < 9) atomicAdd(dL_dsplat + (size_t)s_id[j] * GSR_GRAD_WORDS + lane, v);
       }

@@ -357,7 +357,27 @@ __global__ void __launch_bounds__(kBlock, 4) preprocess_bwd_kernel(BwdArgs a) {
   const bool vis = valid && (int)r3.z > 0;
   const float4* gsp = reinterpret_cast<const float4*>(a.dL_dsplat) + (size_t)i * (GSR_GRAD_WORDS / 4);
   float4 g0 = make_float4(0, 0, 0, 0), g1 = g0, g2 = g0;
-  if (vis) { g0 = gsp[0]; g1 = gsp[1]; g2 = gsp[2]; }
+  if (vis) {
+    // The blend backward leaves moments of u = dL/dG * G over each splat's pixels:
+    //   (sum u, sum u dx, sum u dy, sum u dx^2, sum u dx dy, sum u dy^2, dr, dg, db)
+    // with d = splat centre - pixel.  With the conic (A,B,C) and opacity o of the record:
+    //   dL/dopacity = sum u / o
+    //   dL/dmean2D  = -(A sum u dx + B sum u dy) * W/2,  -(C sum u dy + B sum u dx) * H/2
+    //   dL/d(A,B,C) = (-1/2 sum u dx^2, -sum u dx dy, -1/2 sum u dy^2)
+    const float4 m0 = gsp[0], m1 = gsp[1];
+    g2 = gsp[2];
+    const uint4 r1 = reinterpret_cast<const uint4*>(a.records)[(size_t)i * 4 + 1];
+    const float cA = __uint_as_float(r1.x), cB = __uint_as_float(r1.y), cC = __uint_as_float(r1.z);
+    const float op = __uint_as_float(r1.w);
+    g0.x = -(cA * m0.y + cB * m0.z) * (0.5f * (float)a.W);
+    g0.y = -(cC * m0.z + cB * m0.y) * (0.5f * (float)a.H);
+    g0.z = -0.5f * m0.w;
+    g0.w = -m1.x;
+    g1.x = -0.5f * m1.y;
+    g1.y = m0.x / op;
+    g1.z = m1.z;
+    g1.w = m1.w;
+  }
   // g0 = (dmean2D.x, dmean2D.y, dA, dB); g1 = (dC, dopacity, dr, dg); g2 = (db, -, -, -)
   float dmean[3] = {0.f, 0.f, 0.f};
   float dc6[6] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f};

@@ -262,6 +262,20 @@ def blend_backward(st: ForwardState, grad_color: torch.Tensor) -> torch.Tensor:
     return dsplat
 
 
+def splat_sums_to_grads(st: ForwardState, dsplat: torch.Tensor) -> dict:
+    """The linear map gsr_preprocess_bwd applies to the (P,16) moment sums of the blend
+    backward, in PyTorch: screen-space gradients per Gaussian, for inspection and tests."""
+    co = st.conic_opacity
+    A, B, Cc, o = co[:, 0], co[:, 1], co[:, 2], co[:, 3]
+    m = dsplat
+    vis = st.radii > 0
+    z = torch.zeros_like(A)
+    mean2D = torch.stack([-(A * m[:, 1] + B * m[:, 2]) * (0.5 * st.W), -(Cc * m[:, 2] + B * m[:, 1]) * (0.5 * st.H)], 1)
+    conic = torch.stack([-0.5 * m[:, 3], -m[:, 4], -0.5 * m[:, 5]], 1)
+    return dict(mean2D=torch.where(vis[:, None], mean2D, z[:, None]), conic=torch.where(vis[:, None], conic, z[:, None]),
+                opacity=torch.where(vis, m[:, 0] / o, z), color=torch.where(vis[:, None], m[:, 6:9], z[:, None]))
+
+
 def rasterize_backward(s: GaussianRasterizationSettings, st: ForwardState, grad_color, means3D, shs=None,
                        scales=None, rotations=None, cov3D_precomp=None, dsplat=None):
     """Gradients of every differentiable input, as a dict."""

@@ -145,11 +145,12 @@ int gsr_blend_fwd(int W, int H, const uint32_t* ranges, const uint32_t* point_li
  * dL_dpix (3,H,W) -> per-Gaussian sums, accumulated into dL_dsplat (P,16) fp32
  * (one 64-byte-aligned row per Gaussian, so that the nine sums of a splat leave
  * a wave as ONE atomic request) which the caller zero-fills first and which
- * must be 64-byte aligned: words 0-1 dL/dmean2D in NDC-scaled units
- * (x by W/2, y by H/2; this is what the reference reads from the .grad of its
- * screenspace_points sink, gaussian_renderer/__init__.py:26-30,
- * scene/gaussian_model.py:405-407), 2-4 dL/d(conic A,B,C), 5 dL/dopacity,
- * 6-8 dL/dcolour, 9-15 unused. */
+ * must be 64-byte aligned.  With u = dL/dG * G per (pixel, splat) and
+ * d = splat centre - pixel, the words are the moments
+ *   0: sum u   1: sum u dx   2: sum u dy   3: sum u dx^2   4: sum u dx dy
+ *   5: sum u dy^2   6-8: dL/dcolour   9-15: unused
+ * from which gsr_preprocess_bwd forms dL/dopacity, dL/dmean2D and dL/dconic
+ * once per Gaussian (they are linear in the moments). */
 #define GSR_GRAD_WORDS 16
 int gsr_blend_bwd(int W, int H, const uint32_t* ranges, const uint32_t* point_list,
                   const uint32_t* records, const float* bg, const float* final_T,

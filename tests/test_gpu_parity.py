@@ -124,10 +124,10 @@ def test_backward(oracle32, name):
     g = dgr.rasterize_backward(s_gpu, st, dLg, c.xyz, shs=c.features, scales=c.scaling, rotations=c.rotation,
                                dsplat=dsplat)
     torch.cuda.synchronize()
-    ds = dsplat.cpu().numpy()
+    ds = {k: v.cpu().numpy() for k, v in dgr.splat_sums_to_grads(st, dsplat).items()}
     bb = g_ref["blend"]
-    for nm, got, want in [("mean2D", ds[:, 0:2], bb["dL_dmean2D"]), ("conic", ds[:, 2:5], bb["dL_dconic"]),
-                          ("opacity", ds[:, 5], bb["dL_dopacity"]), ("color", ds[:, 6:9], bb["dL_dcolor"])]:
+    for nm, got, want in [("mean2D", ds["mean2D"], bb["dL_dmean2D"]), ("conic", ds["conic"], bb["dL_dconic"]),
+                          ("opacity", ds["opacity"], bb["dL_dopacity"]), ("color", ds["color"], bb["dL_dcolor"])]:
         e = _rel_err(got, want)
         print(name, "blend_bwd", nm, "rel err %.2e" % e, flush=True)
         assert e < 2e-5, (nm, e)
