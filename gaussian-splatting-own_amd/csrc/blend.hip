@@ -176,30 +176,13 @@ __global__ void __launch_bounds__(256) blend_fwd_kernel(int W, int H, const uint
 // ---------------------------------------------------------------------------
 // backward
 // ---------------------------------------------------------------------------
+constexpr int kRedStride = 80;   // dwords per row of the reduction scratch: 64 lanes + 16, so that two
+                                 // consecutive rows start 16 banks apart (see blend_bwd_kernel)
+
 template <int CTRL>
 __device__ __forceinline__ float dpp_add(float v) {
   const int moved = __builtin_amdgcn_update_dpp(0, __float_as_int(v), CTRL, 0xf, 0xf, false);
   return v + __int_as_float(moved);
-}
-
-// Sum over each row of 16 lanes, left in every lane of the row (4 fused v_add_f32_dpp).
-__device__ __forceinline__ float row_sum(float v) {
-  v = dpp_add<0xB1>(v);    // quad_perm [1,0,3,2]
-  v = dpp_add<0x4E>(v);    // quad_perm [2,3,0,1]
-  v = dpp_add<0x141>(v);   // row_half_mirror
-  v = dpp_add<0x140>(v);   // row_mirror
-  return v;
-}
-
-typedef unsigned uint2v __attribute__((ext_vector_type(2)));
-
-// Sum over the four rows of a wave, lane-wise: lane l ends with v[l%16] summed over the rows.
-// v_permlane16_swap / v_permlane32_swap exchange odd and even rows, then the two 32-lane halves.
-__device__ __forceinline__ float sum_across_rows(float v) {
-  uint2v r = __builtin_amdgcn_permlane16_swap(__float_as_uint(v), __float_as_uint(v), false, false);
-  v = __uint_as_float(r.x) + __uint_as_float(r.y);
-  r = __builtin_amdgcn_permlane32_swap(__float_as_uint(v), __float_as_uint(v), false, false);
-  return __uint_as_float(r.x) + __uint_as_float(r.y);
 }
 
 __global__ void __launch_bounds__(256) blend_bwd_kernel(int W, int H, const uint2* __restrict__ ranges,
@@ -216,6 +199,7 @@ __global__ void __launch_bounds__(256) blend_bwd_kernel(int W, int H, const uint
   __shared__ uint32_t s_id[kBatch];
   __shared__ unsigned long long s_mask[4][4];
   __shared__ int s_last[4];
+  __shared__ __align__(16) float s_red[4][9 * kRedStride];   // per wave: 9 rows of 64 lane values
 
   const Pixel px = my_pixel(W, H);
   const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
@@ -243,6 +227,7 @@ __global__ void __launch_bounds__(256) blend_bwd_kernel(int W, int H, const uint
   // acc = colour composited behind the current splat (everything already visited in this
   // back-to-front walk), per channel.
   float T = Tf, acc0 = 0.f, acc1 = 0.f, acc2 = 0.f;
+  float* red = s_red[wave];
 
   for (int b = (tile_last - 1) / kBatch; b >= 0; b--) {
     __syncthreads();
@@ -304,20 +289,35 @@ __global__ void __launch_bounds__(256) blend_bwd_kernel(int W, int H, const uint
         float u = (co.y * dL_dalpha) * G;
         u = hit ? u : 0.0f;
         const float ux = u * dx, uy = u * dy;
-        float g0 = u, g1 = ux, g2 = uy, g3 = ux * dx, g4 = ux * dy, g5 = uy * dy;
-        float g6 = dch * dp0, g7 = dch * dp1, g8 = dch * dp2;
-        // Nine sums over 64 lanes: reduce each within its row of 16 (every lane of a row then
-        // holds the nine row sums), let lane k of every row keep sum k, and add the four rows
-        // lane-wise.  Lanes 0..8 then issue ONE wave-instruction on nine consecutive dwords of
-        // one 64-byte row = one atomic request.
-        g0 = row_sum(g0); g1 = row_sum(g1); g2 = row_sum(g2); g3 = row_sum(g3); g4 = row_sum(g4);
-        g5 = row_sum(g5); g6 = row_sum(g6); g7 = row_sum(g7); g8 = row_sum(g8);
-        const int k = lane & 15;
-        float v = g0;
-        v = k == 1 ? g1 : v; v = k == 2 ? g2 : v; v = k == 3 ? g3 : v; v = k == 4 ? g4 : v;
-        v = k == 5 ? g5 : v; v = k == 6 ? g6 : v; v = k == 7 ? g7 : v; v = k == 8 ? g8 : v;
-        v = sum_across_rows(v);
-        if (lane < 9) atomicAdd(dL_dsplat + (size_t)s_id[j] * GSR_GRAD_WORDS + lane, v);
+        // Nine sums over the wave's 64 lanes.  Cross-lane VALU operations (DPP) are the expensive
+        // way to do this on gfx950 (36 of them cost as much as the rest of the loop), so the sums
+        // are transposed through LDS instead: every lane stores its nine values as columns
+        // (conflict-free), then lane 8k+s adds up every eighth pair of row k (elements 2s+16t, 2s+16t+1)
+        // with four 8-byte reads that are conflict-free for a row stride of 80 dwords, and three DPP
+        // steps combine the eight lanes of a row.  Row 8 is summed the same way by every group of
+        // eight lanes.  A wave's LDS operations execute in order, so no barrier is needed.
+        red[0 * kRedStride + lane] = u;
+        red[1 * kRedStride + lane] = ux;
+        red[2 * kRedStride + lane] = uy;
+        red[3 * kRedStride + lane] = ux * dx;
+        red[4 * kRedStride + lane] = ux * dy;
+        red[5 * kRedStride + lane] = uy * dy;
+        red[6 * kRedStride + lane] = dch * dp0;
+        red[7 * kRedStride + lane] = dch * dp1;
+        red[8 * kRedStride + lane] = dch * dp2;
+        const float2* rp = reinterpret_cast<const float2*>(red + (lane >> 3) * kRedStride) + (lane & 7);
+        const float2* rq = reinterpret_cast<const float2*>(red + 8 * kRedStride) + (lane & 7);
+        const float2 a0 = rp[0], a1 = rp[8], a2 = rp[16], a3 = rp[24];
+        const float2 b0 = rq[0], b1 = rq[8], b2 = rq[16], b3 = rq[24];
+        float v = ((a0.x + a0.y) + (a1.x + a1.y)) + ((a2.x + a2.y) + (a3.x + a3.y));
+        float v8 = ((b0.x + b0.y) + (b1.x + b1.y)) + ((b2.x + b2.y) + (b3.x + b3.y));
+        v = dpp_add<0xB1>(v); v = dpp_add<0x4E>(v); v = dpp_add<0x141>(v);       // over the 8 segment lanes
+        v8 = dpp_add<0xB1>(v8); v8 = dpp_add<0x4E>(v8); v8 = dpp_add<0x141>(v8);
+        // lane 8k holds sum k (k < 8), every lane holds sum 8: lanes 0,8,..,56 and lane 1 issue ONE
+        // wave-instruction on nine consecutive dwords of one 64-byte row = one atomic request
+        const bool ninth = lane == 1;
+        if ((lane & 7) == 0 || ninth)
+          atomicAdd(dL_dsplat + (size_t)s_id[j] * GSR_GRAD_WORDS + (ninth ? 8 : (lane >> 3)), ninth ? v8 : v);
       }
     }
   }

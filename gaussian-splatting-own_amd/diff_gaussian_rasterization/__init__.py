@@ -27,7 +27,8 @@ import torch
 from torch import nn
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-_LIB_PATH = os.path.join(_HERE, "libgsr_hip.so")
+# GSR_HIP_LIB points at another build of the same library (kernel experiments)
+_LIB_PATH = os.environ.get("GSR_HIP_LIB") or os.path.join(_HERE, "libgsr_hip.so")
 
 TILE = 16
 REC_WORDS = 16
