@@ -143,11 +143,12 @@ __global__ void __launch_bounds__(256) blend_fwd_kernel(int W, int H, const uint
           const float blue = s_blue[j];
           const float dx = ga.x - pxf, dy = ga.y - pyf;
           const float p = gauss_exponent(ga.z, ga.w, co.x, dx, dy);
-          float alpha = fminf(GSR_ALPHA_MAX, co.y * __builtin_amdgcn_exp2f(p));
-          alpha = p <= 0.0f ? alpha : 0.0f;
-          alpha = alpha >= GSR_ALPHA_MIN ? alpha : 0.0f;
-          alpha *= live;
-          if (__ballot(alpha > 0.0f) == 0ull) continue;       // no pixel of the quadrant takes this splat
+          // alpha = min(.99, oG) is kept iff the exponent is <= 0 and alpha >= 1/255, i.e. oG >= 1/255
+          float oG = co.y * __builtin_amdgcn_exp2f(p);
+          const bool keep = (p <= 0.0f) & (oG >= GSR_ALPHA_MIN) & (live != 0.0f);
+          if (__ballot(keep) == 0ull) continue;               // no pixel of the quadrant takes this splat
+          oG = keep ? oG : 0.0f;
+          const float alpha = fminf(GSR_ALPHA_MAX, oG);
           const float test_T = T * (1.0f - alpha);            // alpha == 0: exactly T
           const bool stop = test_T < GSR_T_STOP;               // implies alpha > 0 (T >= T_STOP while live)
           const float w = stop ? 0.0f : alpha * T;
@@ -176,13 +177,26 @@ __global__ void __launch_bounds__(256) blend_fwd_kernel(int W, int H, const uint
 // ---------------------------------------------------------------------------
 // backward
 // ---------------------------------------------------------------------------
-constexpr int kRedStride = 80;   // dwords per row of the reduction scratch: 64 lanes + 16, so that two
-                                 // consecutive rows start 16 banks apart (see blend_bwd_kernel)
+// Dwords per row of the backward's reduction scratch: 64 lane values + 32.  With this stride the
+// 16-byte reads of blend_bwd_kernel (lane 8k+s reads dwords 4s..4s+3 and 32+4s..32+4s+3 of row k)
+// touch 64 distinct banks in each of ds_read_b128's four groups of 16 lanes.
+constexpr int kRedStride = 96;
 
 template <int CTRL>
 __device__ __forceinline__ float dpp_add(float v) {
   const int moved = __builtin_amdgcn_update_dpp(0, __float_as_int(v), CTRL, 0xf, 0xf, false);
   return v + __int_as_float(moved);
+}
+
+typedef unsigned uint2v __attribute__((ext_vector_type(2)));
+
+// Sum over the four rows of a wave, lane-wise: lane l ends with v[l%16] summed over the rows.
+// v_permlane16_swap / v_permlane32_swap exchange odd and even rows, then the two 32-lane halves.
+__device__ __forceinline__ float sum_across_rows(float v) {
+  uint2v r = __builtin_amdgcn_permlane16_swap(__float_as_uint(v), __float_as_uint(v), false, false);
+  v = __uint_as_float(r.x) + __uint_as_float(r.y);
+  r = __builtin_amdgcn_permlane32_swap(__float_as_uint(v), __float_as_uint(v), false, false);
+  return __uint_as_float(r.x) + __uint_as_float(r.y);
 }
 
 __global__ void __launch_bounds__(256) blend_bwd_kernel(int W, int H, const uint2* __restrict__ ranges,
@@ -199,7 +213,7 @@ __global__ void __launch_bounds__(256) blend_bwd_kernel(int W, int H, const uint
   __shared__ uint32_t s_id[kBatch];
   __shared__ unsigned long long s_mask[4][4];
   __shared__ int s_last[4];
-  __shared__ __align__(16) float s_red[4][9 * kRedStride];   // per wave: 9 rows of 64 lane values
+  __shared__ __align__(16) float s_red[4][8 * kRedStride];   // per wave: 8 rows of 64 lane values
 
   const Pixel px = my_pixel(W, H);
   const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
@@ -264,38 +278,37 @@ __global__ void __launch_bounds__(256) blend_bwd_kernel(int W, int H, const uint
         const float4 co = s_col[j];
         const float blue = s_blue[j];
         const float dx = ga.x - pxf, dy = ga.y - pyf;
-        // same alpha and same keep / skip decision as the forward, as straight-line code: a pixel
-        // that did not blend this splat gets alpha = 0, which leaves T and acc unchanged below
+        // same alpha and same keep / skip decision as the forward (min(.99, oG) >= 1/255 exactly when
+        // oG >= 1/255), as straight-line code: a pixel that did not blend this splat gets oG = 0,
+        // hence alpha = 0, which leaves T and acc unchanged below and zeroes its contributions
         const float p = gauss_exponent(ga.z, ga.w, co.x, dx, dy);
-        const float G = __builtin_amdgcn_exp2f(p);
-        float alpha = fminf(GSR_ALPHA_MAX, co.y * G);
-        alpha = p <= 0.0f ? alpha : 0.0f;
-        alpha = alpha >= GSR_ALPHA_MIN ? alpha : 0.0f;
-        alpha = pos < last ? alpha : 0.0f;
-        const bool hit = alpha > 0.0f;
+        float oG = co.y * __builtin_amdgcn_exp2f(p);
+        const bool hit = (p <= 0.0f) & (oG >= GSR_ALPHA_MIN) & (pos < last);
         if (__ballot(hit) == 0ull) continue;
+        oG = hit ? oG : 0.0f;
+        const float alpha = fminf(GSR_ALPHA_MAX, oG);
 
         const float inv = __builtin_amdgcn_rcpf(1.0f - alpha);     // alpha == 0: exactly 1
         T = T * inv;                                               // transmittance in front of the splat
         const float dch = alpha * T;
         const float d0 = co.z - acc0, d1 = co.w - acc1, d2 = blue - acc2;
-        float dL_dalpha = (d0 * dp0 + d1 * dp1 + d2 * dp2) * T - (Tf * inv) * bg_dot;
+        const float dL_dalpha = (d0 * dp0 + d1 * dp1 + d2 * dp2) * T - (Tf * inv) * bg_dot;
         acc0 = fmaf(alpha, d0, acc0);                              // alpha c + (1 - alpha) acc
         acc1 = fmaf(alpha, d1, acc1);
         acc2 = fmaf(alpha, d2, acc2);
         // u = dL/dG * G.  Everything geometric is a moment of u over the pixels:
         //   dL/dopacity = sum u / o,  dL/dmean ~ (sum u dx, sum u dy),  dL/dconic ~ (sum u dx^2, ...)
         // the per-splat factors are applied once per Gaussian by the preprocess backward.
-        float u = (co.y * dL_dalpha) * G;
-        u = hit ? u : 0.0f;
+        const float u = dL_dalpha * oG;
         const float ux = u * dx, uy = u * dy;
         // Nine sums over the wave's 64 lanes.  Cross-lane VALU operations (DPP) are the expensive
         // way to do this on gfx950 (36 of them cost as much as the rest of the loop), so the sums
         // are transposed through LDS instead: every lane stores its nine values as columns
-        // (conflict-free), then lane 8k+s adds up every eighth pair of row k (elements 2s+16t, 2s+16t+1)
-        // with four 8-byte reads that are conflict-free for a row stride of 80 dwords, and three DPP
-        // steps combine the eight lanes of a row.  Row 8 is summed the same way by every group of
-        // eight lanes.  A wave's LDS operations execute in order, so no barrier is needed.
+        // (conflict-free), then lane 8k+s adds up eight elements of row k, fetched with two 16-byte
+        // reads (conflict-free for the row stride chosen above), and three DPP steps combine the
+        // eight lanes of a row.  The ninth sum stays in registers: four DPP steps within the rows of
+        // 16 lanes, two lane-permute swaps across them.  A wave's LDS operations execute in order, so
+        // no barrier is needed.
         red[0 * kRedStride + lane] = u;
         red[1 * kRedStride + lane] = ux;
         red[2 * kRedStride + lane] = uy;
@@ -304,15 +317,13 @@ __global__ void __launch_bounds__(256) blend_bwd_kernel(int W, int H, const uint
         red[5 * kRedStride + lane] = uy * dy;
         red[6 * kRedStride + lane] = dch * dp0;
         red[7 * kRedStride + lane] = dch * dp1;
-        red[8 * kRedStride + lane] = dch * dp2;
-        const float2* rp = reinterpret_cast<const float2*>(red + (lane >> 3) * kRedStride) + (lane & 7);
-        const float2* rq = reinterpret_cast<const float2*>(red + 8 * kRedStride) + (lane & 7);
-        const float2 a0 = rp[0], a1 = rp[8], a2 = rp[16], a3 = rp[24];
-        const float2 b0 = rq[0], b1 = rq[8], b2 = rq[16], b3 = rq[24];
-        float v = ((a0.x + a0.y) + (a1.x + a1.y)) + ((a2.x + a2.y) + (a3.x + a3.y));
-        float v8 = ((b0.x + b0.y) + (b1.x + b1.y)) + ((b2.x + b2.y) + (b3.x + b3.y));
+        const float4* rp = reinterpret_cast<const float4*>(red + (lane >> 3) * kRedStride) + (lane & 7);
+        const float4 a0 = rp[0], a1 = rp[8];
+        float v = ((a0.x + a0.y) + (a0.z + a0.w)) + ((a1.x + a1.y) + (a1.z + a1.w));
+        float v8 = dch * dp2;
         v = dpp_add<0xB1>(v); v = dpp_add<0x4E>(v); v = dpp_add<0x141>(v);       // over the 8 segment lanes
-        v8 = dpp_add<0xB1>(v8); v8 = dpp_add<0x4E>(v8); v8 = dpp_add<0x141>(v8);
+        v8 = dpp_add<0xB1>(v8); v8 = dpp_add<0x4E>(v8); v8 = dpp_add<0x141>(v8); v8 = dpp_add<0x140>(v8);
+        v8 = sum_across_rows(v8);
         // lane 8k holds sum k (k < 8), every lane holds sum 8: lanes 0,8,..,56 and lane 1 issue ONE
         // wave-instruction on nine consecutive dwords of one 64-byte row = one atomic request
         const bool ninth = lane == 1;
