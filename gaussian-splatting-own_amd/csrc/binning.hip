@@ -4,25 +4,29 @@
 // index and row-major tile order, produces.  Ties in (tile, depth) keep
 // ascending Gaussian index.
 //
-// Sorting the N (tile, Gaussian) instances themselves (N ~ 20x the Gaussian
-// count) is pure HBM traffic: 6+ passes over 12-byte pairs for 64-bit keys, or
-// 2 passes over 8-byte pairs for tile-only keys.  Here no per-tile instance is
-// ever sorted.  The rectangle structure is used instead:
-//   1. stable radix sort of the P Gaussians by their 32-bit depth key;
-//   2. every Gaussian, visited in depth order, emits one entry per CELL of its
-//      rectangle, a cell being one tile row x one strip of 16 tiles; an entry
-//      carries the Gaussian index and the rectangle's x range (8 bytes);
-//   3. stable radix sort of the cell entries by cell id (10 bits at 1080p):
-//      NC ~ N/6 entries;
-//   4. each cell list, cut into segments of 2048 entries, is expanded in order:
-//      a counting sweep (wave ballots per tile of the strip), prefix sums over
-//      segments and tiles, then a writing sweep that places every Gaussian index
-//      at tile_start + earlier_segments + earlier_waves + earlier_lanes.
-// The per-tile order is depth order because every step is stable; the tile
-// ranges fall out of the prefix sum.  HBM traffic ~ 4 N (the list itself) plus
-// ~60 NC, instead of ~36 N.
+// Sorting the N (tile, Gaussian) instances themselves (N ~ 20-35x the Gaussian
+// count) is pure HBM traffic: 6+ passes over 12-byte pairs.  Here only the P
+// Gaussians are sorted, once, by depth; everything after that is a cascade of
+// STABLE RANGE PARTITIONS that exploits the rectangle structure.  A range
+// partition takes an ordered list whose items each cover a small box of
+// buckets and produces, per bucket, the ordered sub-list of the items covering
+// it.  A block stages a piece of the list in LDS; each of its waves owns some
+// buckets and sweeps the piece 64 items at a time: one ballot tells which items
+// cover the bucket, its popcount is the count, the bits below a lane are that
+// lane's rank.  A counting sweep, one prefix sum over (bucket, piece), then a
+// writing sweep that repeats the ballots.  Three levels:
+//   1. the depth-sorted Gaussians -> one list per SUPERCELL of 16x16 tiles
+//      (40 at 1080p; entries carry index + rectangle local to the supercell);
+//   2. every supercell list -> one list per CELL = tile row x strip of 16 tiles
+//      (entries carry index + x range);
+//   3. every cell list -> the 16 tile lists of the cell, written straight into
+//      point_list in row-major tile order; the tile ranges fall out of the
+//      prefix sum.
+// Every level keeps the input order, so every tile list is in depth order.
+// Work per level ~ items x buckets / 64 wave steps; HBM traffic ~ 4 N bytes
+// (the list itself) + 16 bytes per cell entry.
 //
-// The sorts and the scans are rocPRIM device primitives; the rest is written here.
+// The depth sort is a rocPRIM radix sort; the rest is written here.
 #include <cstring>
 
 #include <rocprim/rocprim.hpp>
@@ -32,18 +36,19 @@
 namespace {
 
 constexpr int kBlock = 256;
-constexpr int kStrip = 16;        // tiles per cell
-constexpr int kSegLen = 2048;     // cell-list entries per segment
+constexpr int kSuper = 16;                 // supercell side in tiles = tiles per cell
+constexpr uint32_t kPiece1 = 2048;         // list entries per block, per level
+constexpr uint32_t kPiece2 = 2048;
+constexpr uint32_t kPiece3 = 4096;
+constexpr int kScanBlock = 1024;
+constexpr int kTotalsBlocks = 256;
 
-inline unsigned bits_for(unsigned n) {  // smallest b with 2^b >= n, at least 1
-  unsigned b = 1;
-  while ((1ull << b) < n) b++;
-  return b;
-}
+typedef unsigned long long u64;
 
 struct Grid {
-  int gx, gy, cx;                 // tiles per row, tile rows, cells per row
-  __host__ __device__ int cells() const { return cx * gy; }
+  int gx, gy, sx, sy;             // tiles per row, tile rows, supercells per row, supercell rows
+  __host__ __device__ int supercells() const { return sx * sy; }
+  __host__ __device__ int cells() const { return sx * gy; }
   __host__ __device__ int tiles() const { return gx * gy; }
 };
 
@@ -51,225 +56,366 @@ inline Grid make_grid(int W, int H) {
   Grid g;
   g.gx = gsr::div_up(W, GSR_TILE_X);
   g.gy = gsr::div_up(H, GSR_TILE_Y);
-  g.cx = gsr::div_up(g.gx, kStrip);
+  g.sx = gsr::div_up(g.gx, kSuper);
+  g.sy = gsr::div_up(g.gy, kSuper);
   return g;
 }
 
-// Number of cells the rectangle of Gaussian g touches (0 when culled).
-struct CellsOf {
-  const uint32_t* records;
-  __device__ __forceinline__ uint32_t operator()(uint32_t g) const {
-    const uint2 rr = *reinterpret_cast<const uint2*>(records + (size_t)g * GSR_REC_WORDS + GSR_REC_RECT_MIN);
-    const uint32_t x0 = rr.x & 0xffffu, y0 = rr.x >> 16, x1 = rr.y & 0xffffu, y1 = rr.y >> 16;
-    if (x1 <= x0 || y1 <= y0) return 0u;
-    return (y1 - y0) * (((x1 - 1) / kStrip) - (x0 / kStrip) + 1);
-  }
-};
+inline uint32_t div_up_u(uint32_t a, uint32_t b) { return (a + b - 1) / b; }
 
-// [0] = sum of tiles_touched (N), [1] = last inclusive cell offset (NC)
-__global__ void totals_kernel(int P, const uint32_t* __restrict__ cell_offsets, uint32_t* __restrict__ totals) {
-  if (threadIdx.x == 0 && blockIdx.x == 0) totals[1] = cell_offsets[P - 1];
+// ---------------------------------------------------------------------------
+// totals: N = tile instances, E1 = supercell entries, E2 = cell entries, V = visible Gaussians
+// ---------------------------------------------------------------------------
+__device__ __forceinline__ uint32_t wave_sum(uint32_t v) {
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o);
+  return v;
 }
 
-__global__ void __launch_bounds__(kBlock) emit_cells_kernel(int P, Grid grid, const uint32_t* __restrict__ records,
-                                                            const uint32_t* __restrict__ order,
-                                                            const uint32_t* __restrict__ cell_offsets,
-                                                            uint32_t* __restrict__ keys,
-                                                            unsigned long long* __restrict__ vals) {
-  const int j = blockIdx.x * kBlock + threadIdx.x;
-  if (j >= P) return;
-  const uint32_t end = cell_offsets[j], begin = j == 0 ? 0u : cell_offsets[j - 1];
-  if (end == begin) return;
-  const uint32_t g = order[j];
-  const uint2 rr = *reinterpret_cast<const uint2*>(records + (size_t)g * GSR_REC_WORDS + GSR_REC_RECT_MIN);
-  const uint32_t x0 = rr.x & 0xffffu, y0 = rr.x >> 16, x1 = rr.y & 0xffffu, y1 = rr.y >> 16;
-  const uint32_t s0 = x0 / kStrip, s1 = (x1 - 1) / kStrip;
-  const unsigned long long v = (unsigned long long)g | ((unsigned long long)x0 << 32) | ((unsigned long long)x1 << 48);
-  uint32_t off = begin;
-  for (uint32_t y = y0; y < y1; y++)
-    for (uint32_t s = s0; s <= s1; s++) {
-      keys[off] = y * grid.cx + s;
-      vals[off] = v;
-      off++;
+// Every block leaves its four partial sums in partials[4 * block + k]; no atomics.
+__global__ void __launch_bounds__(kBlock) totals_partial_kernel(int P, const uint2* __restrict__ rects,
+                                                                uint32_t* __restrict__ partials) {
+  __shared__ uint32_t s_part[4][4];
+  uint32_t n = 0, e1 = 0, e2 = 0, v = 0;
+  for (int i = blockIdx.x * kBlock + threadIdx.x; i < P; i += gridDim.x * kBlock) {
+    const uint2 r = rects[i];
+    const uint32_t x0 = r.x & 0xffffu, y0 = r.x >> 16, x1 = r.y & 0xffffu, y1 = r.y >> 16;
+    if (x1 > x0 && y1 > y0) {
+      const uint32_t strips = ((x1 - 1) / kSuper) - (x0 / kSuper) + 1;
+      const uint32_t bands = ((y1 - 1) / kSuper) - (y0 / kSuper) + 1;
+      n += (x1 - x0) * (y1 - y0);
+      e1 += strips * bands;
+      e2 += strips * (y1 - y0);
+      v += 1;
     }
+  }
+  n = wave_sum(n); e1 = wave_sum(e1); e2 = wave_sum(e2); v = wave_sum(v);
+  const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+  if (lane == 0) { s_part[wave][0] = n; s_part[wave][1] = e1; s_part[wave][2] = e2; s_part[wave][3] = v; }
+  __syncthreads();
+  if (threadIdx.x < 4)
+    partials[4 * blockIdx.x + threadIdx.x] =
+        s_part[0][threadIdx.x] + s_part[1][threadIdx.x] + s_part[2][threadIdx.x] + s_part[3][threadIdx.x];
+}
+
+__global__ void __launch_bounds__(kBlock) totals_final_kernel(int blocks, const uint32_t* __restrict__ partials,
+                                                              uint32_t* __restrict__ totals) {
+  __shared__ uint32_t s_part[4][4];
+  uint32_t acc[4] = {0u, 0u, 0u, 0u};
+  for (int b = threadIdx.x; b < blocks; b += kBlock) {
+    const uint4 p = reinterpret_cast<const uint4*>(partials)[b];
+    acc[0] += p.x; acc[1] += p.y; acc[2] += p.z; acc[3] += p.w;
+  }
+  const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+#pragma unroll
+  for (int k = 0; k < 4; k++) {
+    acc[k] = wave_sum(acc[k]);
+    if (lane == 0) s_part[wave][k] = acc[k];
+  }
+  __syncthreads();
+  if (threadIdx.x < 4)
+    totals[threadIdx.x] = s_part[0][threadIdx.x] + s_part[1][threadIdx.x] + s_part[2][threadIdx.x] + s_part[3][threadIdx.x];
+}
+
+// ---------------------------------------------------------------------------
+// range partition, one level
+// ---------------------------------------------------------------------------
+// A piece is a run of at most kPiece consecutive entries of one parent list.  Its counts
+// live in counts[slot0 + f * np] for bucket f, np = pieces of the parent, so that ONE
+// exclusive prefix sum over the whole array, which is ordered (parent, bucket, piece),
+// turns every count into the absolute output position of that piece's first entry for
+// that bucket.
+struct LevelArgs {
+  Grid g;
+  uint32_t V;                          // level 1: number of visible Gaussians
+  const uint32_t* order;               // level 1: Gaussian indices front to back
+  const uint2* rects;                  // level 1: tile rectangle per Gaussian
+  const u64* in;                       // levels 2, 3: entries of the parent lists
+  const uint32_t* piece_first;         // levels 2, 3: first piece of every parent, [parents + 1]
+  const uint4* desc;                   // levels 2, 3: (parent, start, length, index in parent) per piece
+  uint32_t* counts;                    // counts, after the scan exclusive positions
+  u64* out64;                          // levels 1, 2
+  uint32_t* out32;                     // level 3: point_list
+};
+
+template <int LEVEL> struct Level;
+template <> struct Level<1> { static constexpr uint32_t kPiece = kPiece1; };
+template <> struct Level<2> { static constexpr uint32_t kPiece = kPiece2; };
+template <> struct Level<3> { static constexpr uint32_t kPiece = kPiece3; };
+
+__device__ __forceinline__ uint32_t lanes_below(unsigned long long ballot) {
+  return __builtin_amdgcn_mbcnt_hi((uint32_t)(ballot >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)ballot, 0u));
+}
+
+// LDS word per staged entry: lo | (hi - lo) << 8 of the covered bucket interval, for level 1
+// in x (bits 0-15) and y (bits 16-31); level 2 keeps the entry's x range in bits 16-23.
+// Padding entries have lo = 255: no bucket index reaches it.
+constexpr uint32_t kNoBox = 0x000000ffu;
+
+template <int LEVEL, bool WRITE>
+__global__ void __launch_bounds__(kBlock) partition_kernel(LevelArgs a) {
+  constexpr uint32_t L = Level<LEVEL>::kPiece;
+  __shared__ uint32_t s_box[L];
+  __shared__ uint32_t s_idx[WRITE ? L : 1];
+  __shared__ uint32_t s_r0[(WRITE && LEVEL == 1) ? L : 1];   // level 1: rectangle min / max words
+  __shared__ uint32_t s_r1[(WRITE && LEVEL == 1) ? L : 1];
+
+  uint32_t start, len, np, slot0, F, FX;
+  if (LEVEL == 1) {
+    np = (a.V + L - 1) / L;
+    if (blockIdx.x >= np) return;
+    start = blockIdx.x * L;
+    len = min(L, a.V - start);
+    slot0 = blockIdx.x;
+    F = (uint32_t)a.g.supercells();
+    FX = (uint32_t)a.g.sx;
+  } else {
+    const uint32_t parents = LEVEL == 2 ? (uint32_t)a.g.supercells() : (uint32_t)a.g.cells();
+    if (blockIdx.x >= a.piece_first[parents]) return;
+    const uint4 d = a.desc[blockIdx.x];
+    const uint32_t pf0 = a.piece_first[d.x];
+    np = a.piece_first[d.x + 1] - pf0;
+    start = d.y;
+    len = d.z;
+    slot0 = pf0 * kSuper + d.w;
+    F = kSuper;
+    FX = kSuper;
+  }
+
+  // stage the piece
+  const uint32_t padded = (len + 63u) & ~63u;
+  for (uint32_t i = threadIdx.x; i < padded; i += kBlock) {
+    uint32_t box = kNoBox;
+    if (i < len) {
+      if (LEVEL == 1) {
+        const uint32_t g = a.order[start + i];
+        const uint2 r = a.rects[g];
+        const uint32_t x0 = r.x & 0xffffu, y0 = r.x >> 16, x1 = r.y & 0xffffu, y1 = r.y >> 16;
+        const uint32_t bx0 = x0 / kSuper, bx1 = (x1 - 1) / kSuper, by0 = y0 / kSuper, by1 = (y1 - 1) / kSuper;
+        box = bx0 | ((bx1 - bx0) << 8) | (by0 << 16) | ((by1 - by0) << 24);
+        if (WRITE) { s_idx[i] = g; s_r0[i] = r.x; s_r1[i] = r.y; }
+      } else {
+        const u64 e = a.in[start + i];
+        const uint32_t lb = (uint32_t)(e >> 32);
+        if (LEVEL == 2) {
+          const uint32_t y0 = (lb >> 8) & 15u, y1 = (lb >> 12) & 15u;
+          box = y0 | ((y1 - y0) << 8) | ((lb & 0xffu) << 16);
+        } else {
+          const uint32_t x0 = lb & 15u, x1 = (lb >> 4) & 15u;
+          box = x0 | ((x1 - x0) << 8);
+        }
+        if (WRITE) s_idx[i] = (uint32_t)e;
+      }
+    }
+    s_box[i] = box;
+  }
+  __syncthreads();
+
+  const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+  const uint32_t per_wave = (F + 3u) / 4u;
+  const uint32_t f_end = min(F, (wave + 1) * per_wave);
+  for (uint32_t fb = wave * per_wave; fb < f_end; fb += 8) {
+    const uint32_t nb = min(8u, f_end - fb);
+    uint32_t run[8], fx[8], fy[8];
+#pragma unroll
+    for (int j = 0; j < 8; j++) {
+      const uint32_t f = fb + j;
+      fx[j] = LEVEL == 1 ? f % FX : f;
+      fy[j] = LEVEL == 1 ? f / FX : 0u;
+      run[j] = 0u;
+      if (WRITE && (uint32_t)j < nb) run[j] = a.counts[slot0 + f * np];
+    }
+    for (uint32_t base = 0; base < len; base += 64) {
+      const uint32_t w = s_box[base + lane];
+      const uint32_t lo = w & 0xffu, wd = (w >> 8) & 0xffu, lo2 = (w >> 16) & 0xffu, wd2 = w >> 24;
+      uint32_t idx = 0u, r0 = 0u, r1 = 0u;
+      if (WRITE) {
+        idx = s_idx[base + lane];
+        if (LEVEL == 1) { r0 = s_r0[base + lane]; r1 = s_r1[base + lane]; }
+      }
+#pragma unroll
+      for (int j = 0; j < 8; j++) {
+        if ((uint32_t)j < nb) {
+          bool hit = (fx[j] - lo) <= wd;
+          if (LEVEL == 1) hit = hit && ((fy[j] - lo2) <= wd2);
+          const unsigned long long bal = __ballot(hit);
+          if (WRITE && hit) {
+            const uint32_t pos = run[j] + lanes_below(bal);
+            if (LEVEL == 1) {
+              // rectangle clipped to the supercell, in tiles relative to its corner, 4 bits each
+              const uint32_t cx = fx[j] * kSuper, cy = fy[j] * kSuper;
+              const uint32_t x0 = r0 & 0xffffu, y0 = r0 >> 16, x1 = (r1 & 0xffffu) - 1u, y1 = (r1 >> 16) - 1u;
+              const uint32_t lx0 = max(x0, cx) - cx, lx1 = min(x1, cx + kSuper - 1u) - cx;
+              const uint32_t ly0 = max(y0, cy) - cy, ly1 = min(y1, cy + kSuper - 1u) - cy;
+              a.out64[pos] = (u64)idx | ((u64)(lx0 | (lx1 << 4) | (ly0 << 8) | (ly1 << 12)) << 32);
+            } else if (LEVEL == 2) {
+              a.out64[pos] = (u64)idx | ((u64)lo2 << 32);
+            } else {
+              a.out32[pos] = idx;
+            }
+          }
+          run[j] += (uint32_t)__popcll(bal);
+        }
+      }
+    }
+    if (!WRITE && lane == 0) {
+#pragma unroll
+      for (int j = 0; j < 8; j++)
+        if ((uint32_t)j < nb) a.counts[slot0 + (fb + j) * np] = run[j];
+    }
+  }
+}
+
+// ---------------------------------------------------------------------------
+// prefix sums between the sweeps: one block each
+// ---------------------------------------------------------------------------
+// In-place exclusive prefix sum of a[0..n) by one block of kScanBlock threads; every thread
+// gets the total.  a must be 16-byte aligned.
+__device__ uint32_t block_scan_inplace(uint32_t* a, uint32_t n, uint32_t* s_wave /* kScanBlock / 64 words */) {
+  const int t = threadIdx.x, lane = t & 63, w = t >> 6;
+  uint32_t carry = 0;
+  for (uint32_t base = 0; base < n; base += 4 * kScanBlock) {
+    const uint32_t i = base + 4 * t;
+    uint4 v = make_uint4(0u, 0u, 0u, 0u);
+    if (i + 3 < n) {
+      v = *reinterpret_cast<const uint4*>(a + i);
+    } else {
+      if (i < n) v.x = a[i];
+      if (i + 1 < n) v.y = a[i + 1];
+      if (i + 2 < n) v.z = a[i + 2];
+    }
+    const uint32_t s = v.x + v.y + v.z + v.w;
+    uint32_t inc = s;
+#pragma unroll
+    for (int o = 1; o < 64; o <<= 1) {
+      const uint32_t u = __shfl_up(inc, o);
+      if (lane >= o) inc += u;
+    }
+    if (lane == 63) s_wave[w] = inc;
+    __syncthreads();
+    uint32_t before = 0, tot = 0;
+#pragma unroll
+    for (int k = 0; k < kScanBlock / 64; k++) {
+      const uint32_t x = s_wave[k];
+      before += k < w ? x : 0u;
+      tot += x;
+    }
+    const uint32_t ex = carry + before + inc - s;
+    const uint4 o4 = make_uint4(ex, ex + v.x, ex + v.x + v.y, ex + v.x + v.y + v.z);
+    if (i + 3 < n) {
+      *reinterpret_cast<uint4*>(a + i) = o4;
+    } else {
+      if (i < n) a[i] = o4.x;
+      if (i + 1 < n) a[i + 1] = o4.y;
+      if (i + 2 < n) a[i + 2] = o4.z;
+    }
+    carry += tot;
+    __syncthreads();
+  }
+  return carry;
+}
+
+// Largest b with first[b] <= q (first is non-decreasing, first[0] = 0, first[n] > q).
+__device__ __forceinline__ uint32_t owner_of(const uint32_t* first, uint32_t n, uint32_t q) {
+  uint32_t lo = 0, hi = n;
+  while (hi - lo > 1) {
+    const uint32_t mid = (lo + hi) >> 1;
+    if (first[mid] <= q) lo = mid; else hi = mid;
+  }
+  return lo;
+}
+
+// Cuts the lists (list_start, list_len)[0..n) into pieces of at most piece_len entries:
+// piece_first (n + 1 words, holds the piece counts on entry) and the descriptors.
+__device__ void build_pieces(uint32_t n, const uint32_t* list_start, const uint32_t* list_len, uint32_t piece_len,
+                             uint32_t* piece_first, uint4* desc, uint32_t* s_wave) {
+  __syncthreads();
+  const uint32_t pieces = block_scan_inplace(piece_first, n + 1, s_wave);
+  __syncthreads();
+  for (uint32_t q = threadIdx.x; q < pieces; q += kScanBlock) {
+    const uint32_t b = owner_of(piece_first, n, q);
+    const uint32_t j = q - piece_first[b];
+    const uint32_t len = list_len[b];
+    desc[q] = make_uint4(b, list_start[b] + j * piece_len, min(piece_len, len - j * piece_len), j);
+  }
+}
+
+// After the level-1 counting sweep: positions, the supercell lists, the level-2 pieces.
+__global__ void __launch_bounds__(kScanBlock) scan1_kernel(Grid g, uint32_t V, uint32_t* counts, uint32_t* list_start,
+                                                           uint32_t* list_len, uint32_t* piece_first, uint4* desc) {
+  __shared__ uint32_t s_wave[kScanBlock / 64];
+  const uint32_t F = (uint32_t)g.supercells(), np = (V + kPiece1 - 1) / kPiece1, slots = np * F;
+  const uint32_t total = block_scan_inplace(counts, slots, s_wave);
+  __syncthreads();
+  for (uint32_t b = threadIdx.x; b < F; b += kScanBlock) {
+    const uint32_t begin = np ? counts[b * np] : 0u;
+    const uint32_t end = (np && b + 1 < F) ? counts[(b + 1) * np] : total;
+    list_start[b] = begin;
+    list_len[b] = end - begin;
+    piece_first[b] = (end - begin + kPiece2 - 1) / kPiece2;
+  }
+  if (threadIdx.x == 0) piece_first[F] = 0u;
+  build_pieces(F, list_start, list_len, kPiece2, piece_first, desc, s_wave);
+}
+
+// After the level-2 counting sweep: positions, the cell lists (row-major cell ids), the level-3 pieces.
+__global__ void __launch_bounds__(kScanBlock) scan2_kernel(Grid g, const uint32_t* piece_first2, uint32_t* counts,
+                                                           uint32_t* list_start, uint32_t* list_len,
+                                                           uint32_t* piece_first, uint4* desc) {
+  __shared__ uint32_t s_wave[kScanBlock / 64];
+  const uint32_t parents = (uint32_t)g.supercells();
+  const uint32_t slots = piece_first2[parents] * kSuper;
+  const uint32_t total = block_scan_inplace(counts, slots, s_wave);
+  __syncthreads();
+  for (uint32_t q = threadIdx.x; q < parents * kSuper; q += kScanBlock) {
+    const uint32_t p = q / kSuper, f = q % kSuper;
+    const uint32_t y = (p / g.sx) * kSuper + f;
+    if (y >= (uint32_t)g.gy) continue;
+    const uint32_t pf0 = piece_first2[p], np = piece_first2[p + 1] - pf0;
+    uint32_t begin = 0u, end = 0u;
+    if (np) {
+      const uint32_t s0 = pf0 * kSuper + f * np;
+      begin = counts[s0];
+      end = s0 + np < slots ? counts[s0 + np] : total;
+    }
+    const uint32_t cell = y * g.sx + p % g.sx;
+    list_start[cell] = begin;
+    list_len[cell] = end - begin;
+    piece_first[cell] = (end - begin + kPiece3 - 1) / kPiece3;
+  }
+  if (threadIdx.x == 0) piece_first[g.cells()] = 0u;
+  build_pieces((uint32_t)g.cells(), list_start, list_len, kPiece3, piece_first, desc, s_wave);
+}
+
+// After the level-3 counting sweep: positions in point_list and the tile ranges,
+// [start, end) per tile, (0,0) for empty tiles.
+__global__ void __launch_bounds__(kScanBlock) scan3_kernel(Grid g, const uint32_t* piece_first3, uint32_t* counts,
+                                                           uint32_t* ranges) {
+  __shared__ uint32_t s_wave[kScanBlock / 64];
+  const uint32_t parents = (uint32_t)g.cells();
+  const uint32_t slots = piece_first3[parents] * kSuper;
+  const uint32_t total = block_scan_inplace(counts, slots, s_wave);
+  __syncthreads();
+  for (uint32_t q = threadIdx.x; q < parents * kSuper; q += kScanBlock) {
+    const uint32_t c = q / kSuper, f = q % kSuper;
+    const uint32_t x = (c % g.sx) * kSuper + f, y = c / g.sx;
+    if (x >= (uint32_t)g.gx) continue;
+    const uint32_t pf0 = piece_first3[c], np = piece_first3[c + 1] - pf0;
+    uint32_t begin = 0u, end = 0u;
+    if (np) {
+      const uint32_t s0 = pf0 * kSuper + f * np;
+      begin = counts[s0];
+      end = s0 + np < slots ? counts[s0 + np] : total;
+    }
+    const uint32_t t = y * g.gx + x;
+    ranges[2 * t] = end > begin ? begin : 0u;
+    ranges[2 * t + 1] = end > begin ? end : 0u;
+  }
 }
 
 __global__ void __launch_bounds__(kBlock) zero_u32_kernel(uint32_t* p, size_t n) {
   const size_t i = (size_t)blockIdx.x * kBlock + threadIdx.x;
   if (i < n) p[i] = 0u;
-}
-
-// [first, last+1) of every key value in a sorted key array; untouched (zero) for absent keys.
-__global__ void __launch_bounds__(kBlock) key_ranges_kernel(uint32_t n, const uint32_t* __restrict__ sorted_keys,
-                                                            uint32_t* __restrict__ ranges) {
-  const uint32_t i = blockIdx.x * kBlock + threadIdx.x;
-  if (i >= n) return;
-  const uint32_t t = sorted_keys[i];
-  if (i == 0) {
-    ranges[2 * t] = 0u;
-  } else {
-    const uint32_t prev = sorted_keys[i - 1];
-    if (t != prev) {
-      ranges[2 * prev + 1] = i;
-      ranges[2 * t] = i;
-    }
-  }
-  if (i == n - 1) ranges[2 * t + 1] = n;
-}
-
-// Cuts every cell list into segments of kSegLen entries.  One block; cells are
-// few (hundreds to a few thousand).  seg_first[c] = index of cell c's first
-// segment, seg_first[cells] = number of segments; seg_desc[s] = (cell, start, len).
-__global__ void __launch_bounds__(1024) build_segments_kernel(int cells, const uint32_t* __restrict__ cell_ranges,
-                                                              uint32_t* __restrict__ seg_first,
-                                                              uint32_t* __restrict__ seg_desc) {
-  __shared__ uint32_t scan[1024];
-  __shared__ uint32_t carry;
-  if (threadIdx.x == 0) carry = 0u;
-  __syncthreads();
-  for (int base = 0; base < cells; base += 1024) {
-    const int c = base + (int)threadIdx.x;
-    uint32_t start = 0, len = 0;
-    if (c < cells) { start = cell_ranges[2 * c]; len = cell_ranges[2 * c + 1] - start; }
-    const uint32_t nseg = (len + kSegLen - 1) / kSegLen;
-    scan[threadIdx.x] = nseg;
-    __syncthreads();
-    for (int o = 1; o < 1024; o <<= 1) {
-      const uint32_t add = (int)threadIdx.x >= o ? scan[threadIdx.x - o] : 0u;
-      __syncthreads();
-      scan[threadIdx.x] += add;
-      __syncthreads();
-    }
-    const uint32_t first = carry + scan[threadIdx.x] - nseg;
-    if (c < cells) {
-      seg_first[c] = first;
-      for (uint32_t k = 0; k < nseg; k++) {
-        const uint32_t s = first + k;
-        seg_desc[3 * s] = (uint32_t)c;
-        seg_desc[3 * s + 1] = start + k * kSegLen;
-        seg_desc[3 * s + 2] = min((uint32_t)kSegLen, len - k * kSegLen);
-      }
-    }
-    __syncthreads();
-    if (threadIdx.x == 1023) carry += scan[1023];
-    __syncthreads();
-  }
-  if (threadIdx.x == 0) seg_first[cells] = carry;
-}
-
-// 16-bit mask of the strip's tiles covered by an entry's x range.
-__device__ __forceinline__ uint32_t strip_mask(unsigned long long v, uint32_t xb) {
-  const uint32_t x0 = (uint32_t)(v >> 32) & 0xffffu, x1 = (uint32_t)(v >> 48);
-  const uint32_t lo = max(x0, xb) - xb, hi = min(x1, xb + kStrip) - xb;   // lo < hi <= 16 by construction
-  return ((1u << hi) - 1u) & ~((1u << lo) - 1u);
-}
-
-// Counting sweep: seg_counts[s][t] = entries of segment s covering tile t of its strip.
-__global__ void __launch_bounds__(kBlock) segment_count_kernel(Grid grid, const uint32_t* __restrict__ seg_first,
-                                                               const uint32_t* __restrict__ seg_desc,
-                                                               const unsigned long long* __restrict__ vals,
-                                                               uint32_t* __restrict__ seg_counts) {
-  __shared__ uint32_t part[4][kStrip];
-  const uint32_t s = blockIdx.x;
-  if (s >= seg_first[grid.cells()]) return;
-  const uint32_t cell = seg_desc[3 * s], start = seg_desc[3 * s + 1], len = seg_desc[3 * s + 2];
-  const uint32_t xb = (cell % grid.cx) * kStrip;
-  const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
-  uint32_t cnt[kStrip];
-#pragma unroll
-  for (int t = 0; t < kStrip; t++) cnt[t] = 0u;
-  for (uint32_t i = threadIdx.x; i < (len + kBlock - 1) / kBlock * kBlock; i += kBlock) {
-    const uint32_t m = i < len ? strip_mask(vals[start + i], xb) : 0u;
-#pragma unroll
-    for (int t = 0; t < kStrip; t++) cnt[t] += (uint32_t)__popcll(__ballot((m >> t) & 1u));
-  }
-  if (lane == 0) {
-#pragma unroll
-    for (int t = 0; t < kStrip; t++) part[wave][t] = cnt[t];
-  }
-  __syncthreads();
-  if (threadIdx.x < kStrip)
-    seg_counts[(size_t)s * kStrip + threadIdx.x] =
-        part[0][threadIdx.x] + part[1][threadIdx.x] + part[2][threadIdx.x] + part[3][threadIdx.x];
-}
-
-// Per cell: running sum over its segments -> seg_base (offset of a segment inside each tile's
-// list) and the tile totals.  One wave per cell, lane t < 16 owns tile t of the strip.
-__global__ void __launch_bounds__(64) segment_scan_kernel(Grid grid, const uint32_t* __restrict__ seg_first,
-                                                          const uint32_t* __restrict__ seg_counts,
-                                                          uint32_t* __restrict__ seg_base,
-                                                          uint32_t* __restrict__ tile_counts) {
-  const int cell = blockIdx.x, t = threadIdx.x;
-  if (t >= kStrip) return;
-  const uint32_t s0 = seg_first[cell], s1 = seg_first[cell + 1];
-  uint32_t run = 0;
-  for (uint32_t s = s0; s < s1; s++) {
-    const uint32_t c = seg_counts[(size_t)s * kStrip + t];
-    seg_base[(size_t)s * kStrip + t] = run;
-    run += c;
-  }
-  const int x = (cell % grid.cx) * kStrip + t, y = cell / grid.cx;
-  if (x < grid.gx) tile_counts[y * grid.gx + x] = run;
-}
-
-// ranges[t] = [start, start + count), (0,0) for empty tiles.
-__global__ void __launch_bounds__(kBlock) ranges_kernel(int tiles, const uint32_t* __restrict__ tile_counts,
-                                                        const uint32_t* __restrict__ tile_starts,
-                                                        uint32_t* __restrict__ ranges) {
-  const int t = blockIdx.x * kBlock + threadIdx.x;
-  if (t >= tiles) return;
-  const uint32_t c = tile_counts[t], s = tile_starts[t];
-  ranges[2 * t] = c ? s : 0u;
-  ranges[2 * t + 1] = c ? s + c : 0u;
-}
-
-// Writing sweep: every entry of the segment drops its Gaussian index into each tile it covers,
-// at tile_start + seg_base + (entries of earlier chunks / waves / lanes covering that tile).
-__global__ void __launch_bounds__(kBlock) segment_write_kernel(Grid grid, const uint32_t* __restrict__ seg_first,
-                                                               const uint32_t* __restrict__ seg_desc,
-                                                               const unsigned long long* __restrict__ vals,
-                                                               const uint32_t* __restrict__ seg_base,
-                                                               const uint32_t* __restrict__ tile_starts,
-                                                               uint32_t* __restrict__ point_list) {
-  __shared__ uint32_t cursor[kStrip];
-  __shared__ uint32_t part[4][kStrip];
-  const uint32_t s = blockIdx.x;
-  if (s >= seg_first[grid.cells()]) return;
-  const uint32_t cell = seg_desc[3 * s], start = seg_desc[3 * s + 1], len = seg_desc[3 * s + 2];
-  const uint32_t xb = (cell % grid.cx) * kStrip, y = cell / grid.cx;
-  const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
-  if (threadIdx.x < kStrip) {
-    const uint32_t x = xb + threadIdx.x;
-    cursor[threadIdx.x] = x < (uint32_t)grid.gx ? tile_starts[y * grid.gx + x] + seg_base[(size_t)s * kStrip + threadIdx.x] : 0u;
-  }
-  __syncthreads();
-  const unsigned long long lt = (1ull << lane) - 1ull;
-  for (uint32_t base = 0; base < len; base += kBlock) {
-    const uint32_t i = base + threadIdx.x;
-    unsigned long long v = 0ull;
-    uint32_t m = 0u;
-    if (i < len) { v = vals[start + i]; m = strip_mask(v, xb); }
-    unsigned long long bal[kStrip];
-#pragma unroll
-    for (int t = 0; t < kStrip; t++) {
-      bal[t] = __ballot((m >> t) & 1u);
-      if (lane == 0) part[wave][t] = (uint32_t)__popcll(bal[t]);
-    }
-    __syncthreads();
-    const uint32_t g = (uint32_t)v;
-#pragma unroll
-    for (int t = 0; t < kStrip; t++) {
-      if ((m >> t) & 1u) {
-        uint32_t pos = cursor[t] + (uint32_t)__popcll(bal[t] & lt);
-        for (int w = 0; w < wave; w++) pos += part[w][t];
-        point_list[pos] = g;
-      }
-    }
-    __syncthreads();
-    if (threadIdx.x < kStrip)
-      cursor[threadIdx.x] += part[0][threadIdx.x] + part[1][threadIdx.x] + part[2][threadIdx.x] + part[3][threadIdx.x];
-    __syncthreads();
-  }
 }
 
 // Optional: tile id of every sorted instance (from which the 64-bit sort keys are rebuilt).
@@ -291,177 +437,143 @@ size_t depth_sort_temp_bytes(int P) {
   return bytes;
 }
 
-size_t cell_scan_temp_bytes(int P) {
-  size_t bytes = 0;
-  auto in = rocprim::make_transform_iterator((const uint32_t*)nullptr, CellsOf{nullptr});
-  (void)rocprim::inclusive_scan(nullptr, bytes, in, (uint32_t*)nullptr, (size_t)P, rocprim::plus<uint32_t>());
-  return bytes;
-}
-
-size_t reduce_temp_bytes(int P) {
-  size_t bytes = 0;
-  (void)rocprim::reduce(nullptr, bytes, (const uint32_t*)nullptr, (uint32_t*)nullptr, 0u, (size_t)P,
-                        rocprim::plus<uint32_t>());
-  return bytes;
-}
-
-size_t cell_sort_temp_bytes(uint32_t NC, unsigned bits) {
-  size_t bytes = 0;
-  (void)rocprim::radix_sort_pairs(nullptr, bytes, (const uint32_t*)nullptr, (uint32_t*)nullptr,
-                                  (const unsigned long long*)nullptr, (unsigned long long*)nullptr, (size_t)NC, 0, bits);
-  return bytes;
-}
-
-size_t tile_scan_temp_bytes(int tiles) {
-  size_t bytes = 0;
-  (void)rocprim::exclusive_scan(nullptr, bytes, (const uint32_t*)nullptr, (uint32_t*)nullptr, 0u, (size_t)tiles,
-                                rocprim::plus<uint32_t>());
-  return bytes;
-}
-
-// Scratch layout of gsr_bin_emit, in 256-byte aligned pieces.
-struct EmitLayout {
-  size_t keys, vals, keys_sorted, vals_sorted, cell_ranges, seg_first, seg_desc, seg_counts, seg_base, tile_counts,
-      tile_starts, temp, temp_bytes, total;
-  uint32_t max_segments;
+// Scratch layout of gsr_bin_lists, in 256-byte aligned pieces.
+struct ListsLayout {
+  size_t counts1, list_start2, list_len2, piece_first2, desc2, entries1, counts2;
+  size_t list_start3, list_len3, piece_first3, desc3, entries2, counts3, total;
+  uint32_t pieces1, max_pieces2, max_pieces3;
 };
 
-EmitLayout emit_layout(uint32_t NC, const Grid& g) {
-  EmitLayout L;
+ListsLayout lists_layout(uint32_t V, uint32_t E1, uint32_t E2, const Grid& g) {
+  ListsLayout L;
   size_t o = 0;
   auto take = [&](size_t bytes) { const size_t at = o; o += gsr::align_up(bytes ? bytes : 1, 256); return at; };
-  L.max_segments = NC / kSegLen + (uint32_t)g.cells() + 1;
-  L.keys = take((size_t)NC * 4);
-  L.vals = take((size_t)NC * 8);
-  L.keys_sorted = take((size_t)NC * 4);
-  L.vals_sorted = take((size_t)NC * 8);
-  L.cell_ranges = take((size_t)g.cells() * 8);
-  L.seg_first = take(((size_t)g.cells() + 1) * 4);
-  L.seg_desc = take((size_t)L.max_segments * 12);
-  L.seg_counts = take((size_t)L.max_segments * kStrip * 4);
-  L.seg_base = take((size_t)L.max_segments * kStrip * 4);
-  L.tile_counts = take((size_t)g.tiles() * 4);
-  L.tile_starts = take((size_t)g.tiles() * 4);
-  const size_t a = cell_sort_temp_bytes(NC, bits_for((unsigned)g.cells())), b = tile_scan_temp_bytes(g.tiles());
-  L.temp_bytes = a > b ? a : b;
-  L.temp = take(L.temp_bytes);
+  L.pieces1 = div_up_u(V, kPiece1);
+  L.max_pieces2 = E1 / kPiece2 + (uint32_t)g.supercells() + 1;
+  L.max_pieces3 = E2 / kPiece3 + (uint32_t)g.cells() + 1;
+  L.counts1 = take((size_t)L.pieces1 * g.supercells() * 4);
+  L.list_start2 = take((size_t)g.supercells() * 4);
+  L.list_len2 = take((size_t)g.supercells() * 4);
+  L.piece_first2 = take(((size_t)g.supercells() + 1) * 4);
+  L.desc2 = take((size_t)L.max_pieces2 * 16);
+  L.entries1 = take((size_t)E1 * 8);
+  L.counts2 = take((size_t)L.max_pieces2 * kSuper * 4);
+  L.list_start3 = take((size_t)g.cells() * 4);
+  L.list_len3 = take((size_t)g.cells() * 4);
+  L.piece_first3 = take(((size_t)g.cells() + 1) * 4);
+  L.desc3 = take((size_t)L.max_pieces3 * 16);
+  L.entries2 = take((size_t)E2 * 8);
+  L.counts3 = take((size_t)L.max_pieces3 * kSuper * 4);
   L.total = o + 256;
   return L;
 }
 
 }  // namespace
 
-extern "C" size_t gsr_bin_prepare_bytes(int P) {
-  if (P <= 0) return 256;
-  const size_t keys = gsr::align_up((size_t)P * 4, 256);
-  size_t t = depth_sort_temp_bytes(P);
-  const size_t b = cell_scan_temp_bytes(P), c = reduce_temp_bytes(P);
-  if (b > t) t = b;
-  if (c > t) t = c;
-  return keys + gsr::align_up(t, 256) + 256;
+extern "C" int gsr_bin_totals(int P, const uint32_t* rects, uint32_t* totals, void* stream) {
+  GSR_REQUIRE(P >= 0, "bin_totals: bad P");
+  GSR_REQUIRE(totals && (P == 0 || rects), "bin_totals: null pointer");
+  GSR_REQUIRE(((uintptr_t)totals & 15) == 0, "bin_totals: totals must be 16-byte aligned");
+  hipStream_t st = (hipStream_t)stream;
+  const int blocks = P == 0 ? 0 : (gsr::div_up(P, kBlock) < kTotalsBlocks ? gsr::div_up(P, kBlock) : kTotalsBlocks);
+  if (blocks)
+    hipLaunchKernelGGL(totals_partial_kernel, dim3(blocks), dim3(kBlock), 0, st, P, (const uint2*)rects, totals + 4);
+  hipLaunchKernelGGL(totals_final_kernel, dim3(1), dim3(kBlock), 0, st, blocks, totals + 4, totals);
+  return gsr::check_launch("bin_totals");
 }
 
-extern "C" int gsr_bin_prepare(int P, const uint32_t* records, const uint32_t* depth_keys,
-                               const uint32_t* tiles_touched, uint32_t* order, uint32_t* cell_offsets,
-                               uint32_t* totals, void* scratch, size_t scratch_bytes, void* stream) {
-  GSR_REQUIRE(P >= 0, "bin_prepare: bad P");
+extern "C" size_t gsr_bin_sort_bytes(int P) {
+  if (P <= 0) return 256;
+  return gsr::align_up((size_t)P * 4, 256) + gsr::align_up(depth_sort_temp_bytes(P), 256) + 256;
+}
+
+extern "C" int gsr_bin_sort(int P, const uint32_t* depth_keys, uint32_t* order, void* scratch, size_t scratch_bytes,
+                            void* stream) {
+  GSR_REQUIRE(P >= 0, "bin_sort: bad P");
   if (P == 0) return GSR_OK;
-  GSR_REQUIRE(records && depth_keys && tiles_touched && order && cell_offsets && totals && scratch,
-              "bin_prepare: null pointer");
-  if (scratch_bytes < gsr_bin_prepare_bytes(P) || ((uintptr_t)scratch & 255))
-    return gsr::fail(GSR_E_SCRATCH, "bin_prepare: scratch too small (%zu < %zu) or not 256-byte aligned",
-                     scratch_bytes, gsr_bin_prepare_bytes(P));
-  hipStream_t st = (hipStream_t)stream;
+  GSR_REQUIRE(depth_keys && order && scratch, "bin_sort: null pointer");
+  if (scratch_bytes < gsr_bin_sort_bytes(P) || ((uintptr_t)scratch & 255))
+    return gsr::fail(GSR_E_SCRATCH, "bin_sort: scratch too small (%zu < %zu) or not 256-byte aligned", scratch_bytes,
+                     gsr_bin_sort_bytes(P));
   char* base = (char*)scratch;
   const size_t keys_bytes = gsr::align_up((size_t)P * 4, 256);
   uint32_t* keys_sorted = (uint32_t*)base;
   void* temp = base + keys_bytes;
   size_t temp_bytes = scratch_bytes - keys_bytes;
   hipError_t e = rocprim::radix_sort_pairs<DepthSortConfig>(temp, temp_bytes, depth_keys, keys_sorted,
-                                           rocprim::counting_iterator<uint32_t>(0), order, (size_t)P, 0, 32, st);
-  if (e != hipSuccess) return gsr::fail(GSR_E_LAUNCH, "bin_prepare: depth sort: %s", hipGetErrorString(e));
-  temp_bytes = scratch_bytes - keys_bytes;
-  auto in = rocprim::make_transform_iterator((const uint32_t*)order, CellsOf{records});
-  e = rocprim::inclusive_scan(temp, temp_bytes, in, cell_offsets, (size_t)P, rocprim::plus<uint32_t>(), st);
-  if (e != hipSuccess) return gsr::fail(GSR_E_LAUNCH, "bin_prepare: cell scan: %s", hipGetErrorString(e));
-  temp_bytes = scratch_bytes - keys_bytes;
-  e = rocprim::reduce(temp, temp_bytes, tiles_touched, totals, 0u, (size_t)P, rocprim::plus<uint32_t>(), st);
-  if (e != hipSuccess) return gsr::fail(GSR_E_LAUNCH, "bin_prepare: reduce: %s", hipGetErrorString(e));
-  hipLaunchKernelGGL(totals_kernel, dim3(1), dim3(64), 0, st, P, cell_offsets, totals);
-  return gsr::check_launch("bin_prepare");
+                                           rocprim::counting_iterator<uint32_t>(0), order, (size_t)P, 0, 32,
+                                           (hipStream_t)stream);
+  if (e != hipSuccess) return gsr::fail(GSR_E_LAUNCH, "bin_sort: depth sort: %s", hipGetErrorString(e));
+  return gsr::check_launch("bin_sort");
 }
 
-extern "C" size_t gsr_bin_emit_bytes(int P, uint32_t N, uint32_t NC, int W, int H) {
-  (void)P;
-  if (N == 0 || NC == 0 || W <= 0 || H <= 0) return 256;
-  return emit_layout(NC, make_grid(W, H)).total;
+extern "C" size_t gsr_bin_lists_bytes(uint32_t V, uint32_t E1, uint32_t E2, int W, int H) {
+  if (V == 0 || W <= 0 || H <= 0) return 256;
+  return lists_layout(V, E1, E2, make_grid(W, H)).total;
 }
 
-extern "C" int gsr_bin_emit(int P, uint32_t N, uint32_t NC, int W, int H, const uint32_t* records,
-                            const uint32_t* order, const uint32_t* cell_offsets, uint32_t* point_list,
-                            uint32_t* ranges, uint32_t* tile_ids_sorted, void* scratch, size_t scratch_bytes,
-                            void* stream) {
-  GSR_REQUIRE(P >= 0 && W > 0 && H > 0, "bin_emit: bad sizes");
-  GSR_REQUIRE(ranges, "bin_emit: null ranges");
+extern "C" int gsr_bin_lists(int P, uint32_t V, uint32_t N, uint32_t E1, uint32_t E2, int W, int H,
+                             const uint32_t* rects, const uint32_t* order, uint32_t* point_list, uint32_t* ranges,
+                             uint32_t* tile_ids_sorted, void* scratch, size_t scratch_bytes, void* stream) {
+  GSR_REQUIRE(P >= 0 && W > 0 && H > 0, "bin_lists: bad sizes");
+  GSR_REQUIRE(ranges, "bin_lists: null ranges");
   hipStream_t st = (hipStream_t)stream;
   const Grid g = make_grid(W, H);
-  if (N == 0 || NC == 0 || P == 0) {
+  GSR_REQUIRE(g.sx <= 255 && g.sy <= 255, "bin_lists: image %dx%d too large", W, H);
+  if (N == 0 || V == 0 || P == 0) {
     hipLaunchKernelGGL(zero_u32_kernel, dim3((unsigned)gsr::div_up(2 * g.tiles(), kBlock)), dim3(kBlock), 0, st, ranges,
                        (size_t)2 * g.tiles());
-    return gsr::check_launch("bin_emit");
+    return gsr::check_launch("bin_lists");
   }
-  GSR_REQUIRE(records && order && cell_offsets && point_list && scratch, "bin_emit: null pointer");
-  GSR_REQUIRE(NC <= N, "bin_emit: NC=%u exceeds N=%u", NC, N);
-  const EmitLayout L = emit_layout(NC, g);
+  GSR_REQUIRE(rects && order && point_list && scratch, "bin_lists: null pointer");
+  GSR_REQUIRE(V <= (uint32_t)P && E1 >= V && E2 >= E1 && N >= E2, "bin_lists: inconsistent totals V=%u E1=%u E2=%u N=%u",
+              V, E1, E2, N);
+  const ListsLayout L = lists_layout(V, E1, E2, g);
   if (scratch_bytes < L.total || ((uintptr_t)scratch & 255))
-    return gsr::fail(GSR_E_SCRATCH, "bin_emit: scratch too small (%zu < %zu) or not 256-byte aligned", scratch_bytes,
+    return gsr::fail(GSR_E_SCRATCH, "bin_lists: scratch too small (%zu < %zu) or not 256-byte aligned", scratch_bytes,
                      L.total);
   char* base = (char*)scratch;
-  uint32_t* keys = (uint32_t*)(base + L.keys);
-  unsigned long long* vals = (unsigned long long*)(base + L.vals);
-  uint32_t* keys_sorted = (uint32_t*)(base + L.keys_sorted);
-  unsigned long long* vals_sorted = (unsigned long long*)(base + L.vals_sorted);
-  uint32_t* cell_ranges = (uint32_t*)(base + L.cell_ranges);
-  uint32_t* seg_first = (uint32_t*)(base + L.seg_first);
-  uint32_t* seg_desc = (uint32_t*)(base + L.seg_desc);
-  uint32_t* seg_counts = (uint32_t*)(base + L.seg_counts);
-  uint32_t* seg_base = (uint32_t*)(base + L.seg_base);
-  uint32_t* tile_counts = (uint32_t*)(base + L.tile_counts);
-  uint32_t* tile_starts = (uint32_t*)(base + L.tile_starts);
-  void* temp = base + L.temp;
+  LevelArgs a{};
+  a.g = g;
+  a.V = V;
 
-  hipLaunchKernelGGL(emit_cells_kernel, dim3(gsr::div_up(P, kBlock)), dim3(kBlock), 0, st, P, g, records, order,
-                     cell_offsets, keys, vals);
-  int rc = gsr::check_launch("bin_emit: emit cells");
+  // level 1: depth-sorted Gaussians -> supercell lists
+  a.order = order;
+  a.rects = (const uint2*)rects;
+  a.counts = (uint32_t*)(base + L.counts1);
+  a.out64 = (u64*)(base + L.entries1);
+  hipLaunchKernelGGL((partition_kernel<1, false>), dim3(L.pieces1), dim3(kBlock), 0, st, a);
+  hipLaunchKernelGGL(scan1_kernel, dim3(1), dim3(kScanBlock), 0, st, g, V, a.counts, (uint32_t*)(base + L.list_start2),
+                     (uint32_t*)(base + L.list_len2), (uint32_t*)(base + L.piece_first2), (uint4*)(base + L.desc2));
+  hipLaunchKernelGGL((partition_kernel<1, true>), dim3(L.pieces1), dim3(kBlock), 0, st, a);
+  int rc = gsr::check_launch("bin_lists: level 1");
   if (rc) return rc;
-  size_t temp_bytes = L.temp_bytes;
-  hipError_t e = rocprim::radix_sort_pairs(temp, temp_bytes, (const uint32_t*)keys, keys_sorted,
-                                           (const unsigned long long*)vals, vals_sorted, (size_t)NC, 0,
-                                           bits_for((unsigned)g.cells()), st);
-  if (e != hipSuccess) return gsr::fail(GSR_E_LAUNCH, "bin_emit: cell sort: %s", hipGetErrorString(e));
-  // zero cell ranges and tile counts (adjacent pieces are zeroed separately: they are not contiguous)
-  hipLaunchKernelGGL(zero_u32_kernel, dim3((unsigned)gsr::div_up(2 * g.cells(), kBlock)), dim3(kBlock), 0, st,
-                     cell_ranges, (size_t)2 * g.cells());
-  hipLaunchKernelGGL(zero_u32_kernel, dim3((unsigned)gsr::div_up(g.tiles(), kBlock)), dim3(kBlock), 0, st, tile_counts,
-                     (size_t)g.tiles());
-  hipLaunchKernelGGL(key_ranges_kernel, dim3((NC + kBlock - 1) / kBlock), dim3(kBlock), 0, st, NC, keys_sorted,
-                     cell_ranges);
-  hipLaunchKernelGGL(build_segments_kernel, dim3(1), dim3(1024), 0, st, g.cells(), cell_ranges, seg_first, seg_desc);
-  hipLaunchKernelGGL(segment_count_kernel, dim3(L.max_segments), dim3(kBlock), 0, st, g, seg_first, seg_desc,
-                     vals_sorted, seg_counts);
-  hipLaunchKernelGGL(segment_scan_kernel, dim3(g.cells()), dim3(64), 0, st, g, seg_first, seg_counts, seg_base,
-                     tile_counts);
-  rc = gsr::check_launch("bin_emit: segment kernels");
+
+  // level 2: supercell lists -> cell lists
+  a.in = (const u64*)(base + L.entries1);
+  a.piece_first = (const uint32_t*)(base + L.piece_first2);
+  a.desc = (const uint4*)(base + L.desc2);
+  a.counts = (uint32_t*)(base + L.counts2);
+  a.out64 = (u64*)(base + L.entries2);
+  hipLaunchKernelGGL((partition_kernel<2, false>), dim3(L.max_pieces2), dim3(kBlock), 0, st, a);
+  hipLaunchKernelGGL(scan2_kernel, dim3(1), dim3(kScanBlock), 0, st, g, a.piece_first, a.counts,
+                     (uint32_t*)(base + L.list_start3), (uint32_t*)(base + L.list_len3),
+                     (uint32_t*)(base + L.piece_first3), (uint4*)(base + L.desc3));
+  hipLaunchKernelGGL((partition_kernel<2, true>), dim3(L.max_pieces2), dim3(kBlock), 0, st, a);
+  rc = gsr::check_launch("bin_lists: level 2");
   if (rc) return rc;
-  temp_bytes = L.temp_bytes;
-  e = rocprim::exclusive_scan(temp, temp_bytes, (const uint32_t*)tile_counts, tile_starts, 0u, (size_t)g.tiles(),
-                              rocprim::plus<uint32_t>(), st);
-  if (e != hipSuccess) return gsr::fail(GSR_E_LAUNCH, "bin_emit: tile scan: %s", hipGetErrorString(e));
-  hipLaunchKernelGGL(ranges_kernel, dim3(gsr::div_up(g.tiles(), kBlock)), dim3(kBlock), 0, st, g.tiles(), tile_counts,
-                     tile_starts, ranges);
-  hipLaunchKernelGGL(segment_write_kernel, dim3(L.max_segments), dim3(kBlock), 0, st, g, seg_first, seg_desc,
-                     vals_sorted, seg_base, tile_starts, point_list);
+
+  // level 3: cell lists -> tile lists = point_list
+  a.in = (const u64*)(base + L.entries2);
+  a.piece_first = (const uint32_t*)(base + L.piece_first3);
+  a.desc = (const uint4*)(base + L.desc3);
+  a.counts = (uint32_t*)(base + L.counts3);
+  a.out64 = nullptr;
+  a.out32 = point_list;
+  hipLaunchKernelGGL((partition_kernel<3, false>), dim3(L.max_pieces3), dim3(kBlock), 0, st, a);
+  hipLaunchKernelGGL(scan3_kernel, dim3(1), dim3(kScanBlock), 0, st, g, a.piece_first, a.counts, ranges);
+  hipLaunchKernelGGL((partition_kernel<3, true>), dim3(L.max_pieces3), dim3(kBlock), 0, st, a);
   if (tile_ids_sorted)
     hipLaunchKernelGGL(fill_tile_ids_kernel, dim3(g.tiles()), dim3(kBlock), 0, st, ranges, tile_ids_sorted);
-  return gsr::check_launch("bin_emit: write");
+  return gsr::check_launch("bin_lists: level 3");
 }

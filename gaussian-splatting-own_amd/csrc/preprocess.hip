@@ -202,7 +202,7 @@ struct FwdArgs {
   const float* shs; const float* colors_precomp; const float* cov3D_precomp;
   const float* view; const float* proj; const float* campos;
   float scale_modifier, tanfovx, tanfovy;
-  uint32_t* records; int32_t* radii; uint32_t* tiles_touched; uint32_t* depth_keys;
+  uint32_t* records; int32_t* radii; uint32_t* tiles_touched; uint32_t* depth_keys; uint32_t* rects;
 };
 
 template <int D>
@@ -277,6 +277,7 @@ __global__ void __launch_bounds__(kBlock) preprocess_fwd_kernel(FwdArgs a) {
     a.radii[i] = 0;
     a.tiles_touched[i] = 0;
     a.depth_keys[i] = 0xFFFFFFFFu;
+    reinterpret_cast<uint2*>(a.rects)[i] = make_uint2(0u, 0u);
     rec[3] = make_uint4(0u, 0u, 0u, 0u);
     return;
   }
@@ -311,6 +312,7 @@ __global__ void __launch_bounds__(kBlock) preprocess_fwd_kernel(FwdArgs a) {
   a.radii[i] = radius;
   a.tiles_touched[i] = (uint32_t)((x1 - x0) * (y1 - y0));
   a.depth_keys[i] = __float_as_uint(pv.z);
+  reinterpret_cast<uint2*>(a.rects)[i] = make_uint2((uint32_t)x0 | ((uint32_t)y0 << 16), (uint32_t)x1 | ((uint32_t)y1 << 16));
   rec[0] = make_uint4(__float_as_uint(pxs), __float_as_uint(pys), __float_as_uint(hx), __float_as_uint(hy));
   rec[1] = make_uint4(__float_as_uint(conA), __float_as_uint(conB), __float_as_uint(conC),
                       __float_as_uint(opacity));
@@ -612,12 +614,12 @@ extern "C" int gsr_preprocess_fwd(int P, int D, int M, const float* means3D, con
                                   const float* viewmatrix, const float* projmatrix, const float* campos,
                                   int W, int H, float tanfovx, float tanfovy, int prefiltered,
                                   uint32_t* records, int32_t* radii, uint32_t* tiles_touched,
-                                  uint32_t* depth_keys, void* stream) {
+                                  uint32_t* depth_keys, uint32_t* rects, void* stream) {
   (void)prefiltered;
   GSR_REQUIRE(P >= 0 && W > 0 && H > 0, "preprocess_fwd: bad sizes P=%d W=%d H=%d", P, W, H);
   if (P == 0) return GSR_OK;
   GSR_REQUIRE(means3D && opacities && viewmatrix && projmatrix && campos, "preprocess_fwd: null input");
-  GSR_REQUIRE(records && radii && tiles_touched && depth_keys, "preprocess_fwd: null output");
+  GSR_REQUIRE(records && radii && tiles_touched && depth_keys && rects, "preprocess_fwd: null output");
   GSR_REQUIRE((shs != nullptr) != (colors_precomp != nullptr), "preprocess_fwd: give exactly one of shs / colors_precomp");
   GSR_REQUIRE(((scales != nullptr) && (rotations != nullptr)) != (cov3D_precomp != nullptr),
               "preprocess_fwd: give exactly one of (scales, rotations) / cov3D_precomp");
@@ -626,7 +628,7 @@ extern "C" int gsr_preprocess_fwd(int P, int D, int M, const float* means3D, con
   GSR_REQUIRE(W <= 16 * 65535 && H <= 16 * 65535, "preprocess_fwd: image too large");
   FwdArgs a{0, 0, nullptr, P, M, W, H, means3D, scales, rotations, opacities, shs, colors_precomp, cov3D_precomp,
             viewmatrix, projmatrix, campos, scale_modifier, tanfovx, tanfovy,
-            records, radii, tiles_touched, depth_keys};
+            records, radii, tiles_touched, depth_keys, rects};
   hipStream_t st = (hipStream_t)stream;
   dim3 grid(gsr::div_up(P, kBlock)), block(kBlock);
   const int d = shs ? D : 0;
@@ -696,12 +698,13 @@ extern "C" int gsr_preprocess_fwd_raw(int P, int D, int n_rest, const float* xyz
                                       const float* features_dc, const float* features_rest,
                                       const float* viewmatrix, const float* projmatrix, const float* campos, int W,
                                       int H, float tanfovx, float tanfovy, uint32_t* records, int32_t* radii,
-                                      uint32_t* tiles_touched, uint32_t* depth_keys, void* stream) {
+                                      uint32_t* tiles_touched, uint32_t* depth_keys, uint32_t* rects,
+                                      void* stream) {
   GSR_REQUIRE(P >= 0 && W > 0 && H > 0, "preprocess_fwd_raw: bad sizes P=%d W=%d H=%d", P, W, H);
   if (P == 0) return GSR_OK;
   GSR_REQUIRE(xyz && scaling_raw && rotation_raw && opacity_raw && features_dc && viewmatrix && projmatrix && campos,
               "preprocess_fwd_raw: null input");
-  GSR_REQUIRE(records && radii && tiles_touched && depth_keys, "preprocess_fwd_raw: null output");
+  GSR_REQUIRE(records && radii && tiles_touched && depth_keys && rects, "preprocess_fwd_raw: null output");
   GSR_REQUIRE(D >= 0 && D <= GSR_MAX_SH_DEGREE, "preprocess_fwd_raw: SH degree %d unsupported (0..3)", D);
   GSR_REQUIRE(n_rest >= (D + 1) * (D + 1) - 1 && n_rest <= 15 && (n_rest == 0 || features_rest),
               "preprocess_fwd_raw: n_rest=%d does not hold degree %d", n_rest, D);
@@ -710,7 +713,7 @@ extern "C" int gsr_preprocess_fwd_raw(int P, int D, int n_rest, const float* xyz
   const bool split = n_rest > 0;
   FwdArgs a{1, n_rest, split ? features_rest : nullptr, P, 1 + n_rest, W, H, xyz, scaling_raw, rotation_raw,
             opacity_raw, features_dc, nullptr, nullptr, viewmatrix, projmatrix, campos, scale_modifier, tanfovx,
-            tanfovy, records, radii, tiles_touched, depth_keys};
+            tanfovy, records, radii, tiles_touched, depth_keys, rects};
   hipStream_t st = (hipStream_t)stream;
   dim3 grid(gsr::div_up(P, kBlock)), block(kBlock);
   switch (D) {

@@ -33,6 +33,7 @@ _LIB_PATH = os.environ.get("GSR_HIP_LIB") or os.path.join(_HERE, "libgsr_hip.so"
 TILE = 16
 REC_WORDS = 16
 GRAD_WORDS = 16
+TOTALS_WORDS = 4 + 4 * 256
 
 
 def _load():
@@ -42,22 +43,24 @@ def _load():
             "(or python -c 'import __graft_entry__ as g; g.build()'); there is no non-HIP fallback")
     lib = C.CDLL(_LIB_PATH)
     lib.gsr_last_error.restype = C.c_char_p
-    lib.gsr_bin_prepare_bytes.restype = C.c_size_t
-    lib.gsr_bin_prepare_bytes.argtypes = [C.c_int]
-    lib.gsr_bin_emit_bytes.restype = C.c_size_t
-    lib.gsr_bin_emit_bytes.argtypes = [C.c_int, C.c_uint32, C.c_uint32, C.c_int, C.c_int]
+    lib.gsr_bin_sort_bytes.restype = C.c_size_t
+    lib.gsr_bin_sort_bytes.argtypes = [C.c_int]
+    lib.gsr_bin_lists_bytes.restype = C.c_size_t
+    lib.gsr_bin_lists_bytes.argtypes = [C.c_uint32, C.c_uint32, C.c_uint32, C.c_int, C.c_int]
     vp, ci, cf = C.c_void_p, C.c_int, C.c_float
     lib.gsr_preprocess_fwd.argtypes = [ci, ci, ci, vp, vp, cf, vp, vp, vp, vp, vp, vp, vp, vp, ci, ci, cf, cf, ci,
-                                       vp, vp, vp, vp, vp]
+                                       vp, vp, vp, vp, vp, vp]
     lib.gsr_mark_visible.argtypes = [ci, vp, vp, vp, vp]
-    lib.gsr_bin_prepare.argtypes = [ci, vp, vp, vp, vp, vp, vp, vp, C.c_size_t, vp]
-    lib.gsr_bin_emit.argtypes = [ci, C.c_uint32, C.c_uint32, ci, ci, vp, vp, vp, vp, vp, vp, vp, C.c_size_t, vp]
+    u32 = C.c_uint32
+    lib.gsr_bin_totals.argtypes = [ci, vp, vp, vp]
+    lib.gsr_bin_sort.argtypes = [ci, vp, vp, vp, C.c_size_t, vp]
+    lib.gsr_bin_lists.argtypes = [ci, u32, u32, u32, u32, ci, ci, vp, vp, vp, vp, vp, vp, C.c_size_t, vp]
     lib.gsr_blend_fwd.argtypes = [ci, ci, vp, vp, vp, vp, vp, vp, vp, vp]
     lib.gsr_blend_bwd.argtypes = [ci, ci, vp, vp, vp, vp, vp, vp, vp, vp, vp]
     lib.gsr_preprocess_bwd.argtypes = [ci, ci, ci, vp, vp, cf, vp, vp, vp, vp, vp, vp, ci, ci, cf, cf, vp, vp,
                                        vp, vp, vp, vp, vp, vp, vp, vp, vp]
     lib.gsr_preprocess_fwd_raw.argtypes = [ci, ci, ci, vp, vp, cf, vp, vp, vp, vp, vp, vp, vp, ci, ci, cf, cf,
-                                           vp, vp, vp, vp, vp]
+                                           vp, vp, vp, vp, vp, vp]
     lib.gsr_preprocess_bwd_raw.argtypes = [ci, ci, ci, vp, vp, cf, vp, vp, vp, vp, vp, vp, vp, ci, ci, cf, cf,
                                            vp, vp, vp, vp, vp, vp, vp, vp, vp, vp]
     return lib
@@ -116,6 +119,19 @@ def _stream():
     return C.c_void_p(torch.cuda.current_stream().cuda_stream)
 
 
+_pinned = {}
+
+
+def _pinned_totals(dev: torch.device) -> torch.Tensor:
+    """Page-locked landing buffer for the four list sizes, one per device.  Every forward waits
+    for its own copy before reading it, so successive calls of one thread can share it."""
+    key = (dev.type, dev.index if dev.index is not None else torch.cuda.current_device())
+    buf = _pinned.get(key)
+    if buf is None:
+        buf = _pinned[key] = torch.empty((4,), dtype=torch.int32, pin_memory=True)
+    return buf
+
+
 def _f32(t: Optional[torch.Tensor], name: str) -> Optional[torch.Tensor]:
     if t is None or t.numel() == 0:
         return None
@@ -144,8 +160,8 @@ class GaussianRasterizationSettings(NamedTuple):
 class ForwardState:
     """Everything the forward leaves behind: op outputs, what backward needs,
     and the intermediate buffers the parity tests inspect."""
-    __slots__ = ("P", "M", "D", "W", "H", "records", "radii", "tiles_touched", "depth_keys", "order", "offsets",
-                 "num_rendered", "point_list", "ranges", "tile_ids_sorted", "color", "final_T", "n_contrib",
+    __slots__ = ("P", "M", "D", "W", "H", "records", "radii", "tiles_touched", "depth_keys", "order", "rect_words",
+                 "num_rendered", "num_visible", "point_list", "ranges", "tile_ids_sorted", "color", "final_T", "n_contrib",
                  "view", "proj", "campos", "bg")
 
     # views into the 64-byte records, named as the oracle names them
@@ -207,14 +223,14 @@ def rasterize_forward(s: GaussianRasterizationSettings, means3D, opacities, shs=
     st.tiles_touched = torch.empty((P,), **u32)
     st.depth_keys = torch.empty((P,), **u32)
     st.order = torch.empty((P,), **u32)
-    st.offsets = torch.empty((P,), **u32)
+    st.rect_words = torch.empty((P, 2), **u32)
     gx, gy = (W + TILE - 1) // TILE, (H + TILE - 1) // TILE
     st.ranges = torch.empty((gx * gy, 2), **u32)
     st.color = torch.empty((3, H, W), dtype=torch.float32, device=dev)
     st.final_T = torch.empty((H, W), dtype=torch.float32, device=dev)
     st.n_contrib = torch.empty((H, W), **u32)
     st.tile_ids_sorted = None
-    N = NC = 0
+
     if P > 0 and raw is not None:
         r = {k: _f32(v, k) for k, v in raw.items()}
         n_rest = 0 if r["features_rest"] is None else r["features_rest"].shape[1]
@@ -222,28 +238,36 @@ def rasterize_forward(s: GaussianRasterizationSettings, means3D, opacities, shs=
         _run("preprocess_fwd", _lib.gsr_preprocess_fwd_raw, P, st.D, n_rest, _ptr(means3D), _ptr(r["scaling"]),
              float(s.scale_modifier), _ptr(r["rotation"]), _ptr(r["opacity"]), _ptr(r["features_dc"]),
              _ptr(r["features_rest"]), _ptr(st.view), _ptr(st.proj), _ptr(st.campos), W, H, float(s.tanfovx),
-             float(s.tanfovy), _ptr(st.records), _ptr(st.radii), _ptr(st.tiles_touched), _ptr(st.depth_keys), stream)
+             float(s.tanfovy), _ptr(st.records), _ptr(st.radii), _ptr(st.tiles_touched), _ptr(st.depth_keys),
+             _ptr(st.rect_words), stream)
     elif P > 0:
         _run("preprocess_fwd", _lib.gsr_preprocess_fwd, P, st.D, st.M, _ptr(means3D), _ptr(scales),
              float(s.scale_modifier), _ptr(rotations), _ptr(opacities), _ptr(shs), _ptr(colors_precomp),
              _ptr(cov3D_precomp), _ptr(st.view), _ptr(st.proj), _ptr(st.campos), W, H, float(s.tanfovx),
              float(s.tanfovy), int(bool(s.prefiltered)), _ptr(st.records), _ptr(st.radii), _ptr(st.tiles_touched),
-             _ptr(st.depth_keys), stream)
+             _ptr(st.depth_keys), _ptr(st.rect_words), stream)
+    N = E1 = E2 = V = 0
     if P > 0:
-        nb = _lib.gsr_bin_prepare_bytes(P)
+        # The list sizes go to the host (the pipeline's one read-back) while the GPU sorts by depth:
+        # the copy is queued before the sort and the host waits for the copy alone.
+        totals = torch.empty((TOTALS_WORDS,), **u32)
+        _run("bin_totals", _lib.gsr_bin_totals, P, _ptr(st.rect_words), _ptr(totals), stream)
+        host = _pinned_totals(dev)
+        host.copy_(totals[:4], non_blocking=True)
+        copied = torch.cuda.Event()
+        copied.record()
+        nb = _lib.gsr_bin_sort_bytes(P)
         scratch = torch.empty((nb,), dtype=torch.uint8, device=dev)
-        totals = torch.empty((2,), **u32)
-        _run("bin_prepare", _lib.gsr_bin_prepare, P, _ptr(st.records), _ptr(st.depth_keys), _ptr(st.tiles_touched),
-             _ptr(st.order), _ptr(st.offsets), _ptr(totals), _ptr(scratch), nb, stream)
-        n_nc = totals.tolist()                              # the pipeline's one host read-back
-        N, NC = n_nc[0] & 0xFFFFFFFF, n_nc[1] & 0xFFFFFFFF
-    st.num_rendered = N
+        _run("bin_sort", _lib.gsr_bin_sort, P, _ptr(st.depth_keys), _ptr(st.order), _ptr(scratch), nb, stream)
+        copied.synchronize()
+        N, E1, E2, V = (int(v) & 0xFFFFFFFF for v in host.tolist())
+    st.num_rendered, st.num_visible = N, V
     st.point_list = torch.empty((max(N, 1),), **u32)
     if keep_tile_ids:
         st.tile_ids_sorted = torch.empty((max(N, 1),), **u32)
-    nb = _lib.gsr_bin_emit_bytes(P, N, NC, W, H)
+    nb = _lib.gsr_bin_lists_bytes(V, E1, E2, W, H)
     scratch = torch.empty((nb,), dtype=torch.uint8, device=dev)
-    _run("bin_emit", _lib.gsr_bin_emit, P, N, NC, W, H, _ptr(st.records), _ptr(st.order), _ptr(st.offsets),
+    _run("bin_lists", _lib.gsr_bin_lists, P, V, N, E1, E2, W, H, _ptr(st.rect_words), _ptr(st.order),
          _ptr(st.point_list), _ptr(st.ranges), _ptr(st.tile_ids_sorted), _ptr(scratch), nb, stream)
     _run("blend_fwd", _lib.gsr_blend_fwd, W, H, _ptr(st.ranges), _ptr(st.point_list), _ptr(st.records), _ptr(st.bg),
                               _ptr(st.color), _ptr(st.final_T), _ptr(st.n_contrib), stream)

@@ -21,8 +21,8 @@
  *    aligned.
  *  - `stream` is a hipStream_t passed as void* (NULL = the null stream).
  *    Calls only enqueue work; none synchronises.  The one host read-back the
- *    pipeline needs (the number of tile instances, after gsr_bin_prepare) is
- *    done by the caller.
+ *    pipeline needs (the list sizes, after gsr_bin_totals) is done by the
+ *    caller.
  *  - Return value: 0 = success, negative = error (GSR_E_*); gsr_last_error()
  *    returns a message for the calling thread's last failure.
  *  - Floating tensors are fp32, contiguous.  Layouts follow the reference's
@@ -85,14 +85,16 @@ const char* gsr_last_error(void);
  * stored per Gaussian and channel (>= (D+1)^2).
  * Outputs: records (P,16) words; radii (P) int32 (0 = not visible);
  * tiles_touched (P) uint32; depth_keys (P) uint32 = IEEE bits of view z for
- * visible Gaussians, 0xFFFFFFFF for culled ones. */
+ * visible Gaussians, 0xFFFFFFFF for culled ones; rects (P,2) uint32 = the tile
+ * rectangle as in record words 12-13 (min, exclusive max; x | y << 16), zeros
+ * for culled Gaussians: a compact copy for the binning kernels. */
 int gsr_preprocess_fwd(int P, int D, int M, const float* means3D, const float* scales,
                        float scale_modifier, const float* rotations, const float* opacities,
                        const float* shs, const float* colors_precomp, const float* cov3D_precomp,
                        const float* viewmatrix, const float* projmatrix, const float* campos,
                        int W, int H, float tanfovx, float tanfovy, int prefiltered,
                        uint32_t* records, int32_t* radii, uint32_t* tiles_touched,
-                       uint32_t* depth_keys, void* stream);
+                       uint32_t* depth_keys, uint32_t* rects, void* stream);
 
 /* GaussianRasterizer.markVisible of the module (never called by the
  * reference's Python): present[i] = view-space z > 0.2. */
@@ -104,32 +106,36 @@ int gsr_mark_visible(int P, const float* means3D, const float* viewmatrix, uint8
  * covers it, ordered front to back: the result of the module's
  * duplicateWithKeys -> 64-bit (tile | depth) radix sort -> identifyTileRanges
  * chain, bit for bit (ties in (tile, depth) keep ascending Gaussian index).
- * No per-tile instance is sorted: the Gaussians are depth-sorted (P keys), one
- * entry per CELL (tile row x strip of 16 tiles) of each rectangle is sorted by
- * cell id (NC ~ N/6 entries), and each cell list is expanded in order into its
- * tiles.  Every step is stable, so the lists equal the 64-bit sort's.
+ * No per-tile instance is sorted: the Gaussians are depth-sorted once (P keys),
+ * then three stable range partitions split that list by SUPERCELL (16x16
+ * tiles), by CELL (tile row x strip of 16 tiles) and by tile.  Every step is
+ * stable, so the lists equal the 64-bit sort's.
  *
- * gsr_bin_prepare: depth-sorts the Gaussians, prefix-sums the number of cells
- * each touches in that order, and totals the tile instances.
- * order (P) uint32 = Gaussian indices front to back; cell_offsets (P) uint32 =
- * inclusive prefix sum of cells touched; totals (2) uint32 = { N = number of
- * tile instances, NC = number of cell entries }, which the caller reads back
- * (the pipeline's one host read-back) to size gsr_bin_emit. */
-size_t gsr_bin_prepare_bytes(int P);
-int gsr_bin_prepare(int P, const uint32_t* records, const uint32_t* depth_keys,
-                    const uint32_t* tiles_touched, uint32_t* order, uint32_t* cell_offsets,
-                    uint32_t* totals, void* scratch, size_t scratch_bytes, void* stream);
+ * gsr_bin_totals: totals[0..3] = { N = tile instances (sum of tiles_touched),
+ * E1 = supercell entries, E2 = cell entries, V = visible Gaussians }, from the
+ * rectangles alone.  The caller reads the four words back (the pipeline's one
+ * host read-back; it can overlap gsr_bin_sort) to size gsr_bin_lists.  totals
+ * has GSR_TOTALS_WORDS words (the rest is the call's scratch), 16-byte aligned. */
+#define GSR_TOTALS_WORDS (4 + 4 * 256)
+int gsr_bin_totals(int P, const uint32_t* rects, uint32_t* totals, void* stream);
 
-/* gsr_bin_emit: point_list (N) uint32 = Gaussian index per sorted instance;
- * ranges (tiles,2) uint32 = [start,end) into point_list per tile, (0,0) for
- * empty tiles.  tile_ids_sorted (N) uint32 is optional (may be NULL): the tile
- * id of each sorted instance, from which the module's 64-bit sort keys are
- * (tile << 32) | depth_key[point_list]. */
-size_t gsr_bin_emit_bytes(int P, uint32_t N, uint32_t NC, int W, int H);
-int gsr_bin_emit(int P, uint32_t N, uint32_t NC, int W, int H, const uint32_t* records,
-                 const uint32_t* order, const uint32_t* cell_offsets, uint32_t* point_list,
-                 uint32_t* ranges, uint32_t* tile_ids_sorted, void* scratch,
+/* gsr_bin_sort: order (P) uint32 = Gaussian indices by ascending depth key,
+ * ties by ascending index; the V visible ones come first. */
+size_t gsr_bin_sort_bytes(int P);
+int gsr_bin_sort(int P, const uint32_t* depth_keys, uint32_t* order, void* scratch,
                  size_t scratch_bytes, void* stream);
+
+/* gsr_bin_lists: point_list (N) uint32 = Gaussian index per sorted instance;
+ * ranges (tiles,2) uint32 = [start,end) into point_list per tile, (0,0) for
+ * empty tiles.  V, N, E1, E2 are the values gsr_bin_totals produced.
+ * tile_ids_sorted (N) uint32 is optional (may be NULL): the tile id of each
+ * sorted instance, from which the module's 64-bit sort keys are
+ * (tile << 32) | depth_key[point_list]. */
+size_t gsr_bin_lists_bytes(uint32_t V, uint32_t E1, uint32_t E2, int W, int H);
+int gsr_bin_lists(int P, uint32_t V, uint32_t N, uint32_t E1, uint32_t E2, int W, int H,
+                  const uint32_t* rects, const uint32_t* order, uint32_t* point_list,
+                  uint32_t* ranges, uint32_t* tile_ids_sorted, void* scratch,
+                  size_t scratch_bytes, void* stream);
 
 /* ---- Stage 3: blend forward ----------------------------------------------
  * Front-to-back alpha compositing per tile (the module's per-tile render
@@ -188,7 +194,7 @@ int gsr_preprocess_fwd_raw(int P, int D, int n_rest, const float* xyz, const flo
                            const float* viewmatrix, const float* projmatrix, const float* campos,
                            int W, int H, float tanfovx, float tanfovy, uint32_t* records,
                            int32_t* radii, uint32_t* tiles_touched, uint32_t* depth_keys,
-                           void* stream);
+                           uint32_t* rects, void* stream);
 int gsr_preprocess_bwd_raw(int P, int D, int n_rest, const float* xyz, const float* scaling_raw,
                            float scale_modifier, const float* rotation_raw, const float* opacity_raw,
                            const float* features_dc, const float* features_rest,
