@@ -26,6 +26,10 @@
 // Work per level ~ items x buckets / 64 wave steps; HBM traffic ~ 4 N bytes
 // (the list itself) + 16 bytes per cell entry.
 //
+// Nothing is gathered by index: the depth sort carries, as its 64-bit value, the
+// Gaussian's index packed with its tile rectangle (bit widths chosen per call
+// from P and the tile grid), and that word is what levels 1 and 2 read.
+//
 // The depth sort is a rocPRIM radix sort; the rest is written here.
 #include <cstring>
 
@@ -63,6 +67,39 @@ inline Grid make_grid(int W, int H) {
 
 inline uint32_t div_up_u(uint32_t a, uint32_t b) { return (a + b - 1) / b; }
 
+inline unsigned bits_for(unsigned n) {  // smallest b with 2^b >= n, at least 1
+  unsigned b = 1;
+  while ((1ull << b) < n) b++;
+  return b;
+}
+
+// Layout of the 64-bit word that travels through the depth sort:
+// index | x0 << bi | (x1 - 1) << (bi + bx) | y0 << (bi + 2 bx) | (y1 - 1) << (bi + 2 bx + by).
+struct Pack {
+  uint32_t bi, bx, by;
+  __host__ __device__ uint32_t bits() const { return bi + 2 * bx + 2 * by; }
+  __device__ __forceinline__ u64 pack(uint32_t i, uint32_t x0, uint32_t x1m, uint32_t y0, uint32_t y1m) const {
+    return (u64)i | ((u64)x0 << bi) | ((u64)x1m << (bi + bx)) | ((u64)y0 << (bi + 2 * bx)) |
+           ((u64)y1m << (bi + 2 * bx + by));
+  }
+  __device__ __forceinline__ uint32_t index(u64 v) const { return (uint32_t)(v & ((1ull << bi) - 1ull)); }
+  __device__ __forceinline__ void rect(u64 v, uint32_t& x0, uint32_t& x1m, uint32_t& y0, uint32_t& y1m) const {
+    const uint32_t mx = (1u << bx) - 1u, my = (1u << by) - 1u;
+    x0 = (uint32_t)(v >> bi) & mx;
+    x1m = (uint32_t)(v >> (bi + bx)) & mx;
+    y0 = (uint32_t)(v >> (bi + 2 * bx)) & my;
+    y1m = (uint32_t)(v >> (bi + 2 * bx + by)) & my;
+  }
+};
+
+inline Pack make_pack(int P, const Grid& g) {
+  Pack k;
+  k.bi = bits_for((unsigned)(P > 1 ? P : 2));
+  k.bx = bits_for((unsigned)g.gx);
+  k.by = bits_for((unsigned)g.gy);
+  return k;
+}
+
 // ---------------------------------------------------------------------------
 // totals: N = tile instances, E1 = supercell entries, E2 = cell entries, V = visible Gaussians
 // ---------------------------------------------------------------------------
@@ -73,13 +110,16 @@ __device__ __forceinline__ uint32_t wave_sum(uint32_t v) {
 }
 
 // Every block leaves its four partial sums in partials[4 * block + k]; no atomics.
-__global__ void __launch_bounds__(kBlock) totals_partial_kernel(int P, const uint2* __restrict__ rects,
-                                                                uint32_t* __restrict__ partials) {
+// Also packs index and rectangle of every Gaussian into the word the depth sort carries.
+__global__ void __launch_bounds__(kBlock) totals_partial_kernel(int P, Pack pk, const uint2* __restrict__ rects,
+                                                                uint32_t* __restrict__ partials,
+                                                                u64* __restrict__ sort_vals) {
   __shared__ uint32_t s_part[4][4];
   uint32_t n = 0, e1 = 0, e2 = 0, v = 0;
   for (int i = blockIdx.x * kBlock + threadIdx.x; i < P; i += gridDim.x * kBlock) {
     const uint2 r = rects[i];
     const uint32_t x0 = r.x & 0xffffu, y0 = r.x >> 16, x1 = r.y & 0xffffu, y1 = r.y >> 16;
+    sort_vals[i] = (x1 > x0 && y1 > y0) ? pk.pack((uint32_t)i, x0, x1 - 1, y0, y1 - 1) : (u64)(uint32_t)i;
     if (x1 > x0 && y1 > y0) {
       const uint32_t strips = ((x1 - 1) / kSuper) - (x0 / kSuper) + 1;
       const uint32_t bands = ((y1 - 1) / kSuper) - (y0 / kSuper) + 1;
@@ -127,10 +167,11 @@ __global__ void __launch_bounds__(kBlock) totals_final_kernel(int blocks, const 
 // that bucket.
 struct LevelArgs {
   Grid g;
+  Pack pk;
   uint32_t V;                          // level 1: number of visible Gaussians
-  const uint32_t* order;               // level 1: Gaussian indices front to back
-  const uint2* rects;                  // level 1: tile rectangle per Gaussian
-  const u64* in;                       // levels 2, 3: entries of the parent lists
+  const u64* in;                       // level 1: packed (index, rectangle) words front to back;
+                                       // level 2: the same words per supercell list;
+                                       // level 3: index | (x0 | x1 << 4) << 32, x relative to the cell
   const uint32_t* piece_first;         // levels 2, 3: first piece of every parent, [parents + 1]
   const uint4* desc;                   // levels 2, 3: (parent, start, length, index in parent) per piece
   uint32_t* counts;                    // counts, after the scan exclusive positions
@@ -139,9 +180,11 @@ struct LevelArgs {
 };
 
 template <int LEVEL> struct Level;
-template <> struct Level<1> { static constexpr uint32_t kPiece = kPiece1; };
-template <> struct Level<2> { static constexpr uint32_t kPiece = kPiece2; };
-template <> struct Level<3> { static constexpr uint32_t kPiece = kPiece3; };
+// entries per piece; threads per block (level 1 has many buckets: more waves share a staged piece)
+// and buckets a wave carries through one sweep of the piece
+template <> struct Level<1> { static constexpr uint32_t kPiece = kPiece1; static constexpr int kThreads = 1024, kChunk = 4; };
+template <> struct Level<2> { static constexpr uint32_t kPiece = kPiece2; static constexpr int kThreads = 256, kChunk = 4; };
+template <> struct Level<3> { static constexpr uint32_t kPiece = kPiece3; static constexpr int kThreads = 512, kChunk = 2; };
 
 __device__ __forceinline__ uint32_t lanes_below(unsigned long long ballot) {
   return __builtin_amdgcn_mbcnt_hi((uint32_t)(ballot >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)ballot, 0u));
@@ -153,14 +196,15 @@ __device__ __forceinline__ uint32_t lanes_below(unsigned long long ballot) {
 constexpr uint32_t kNoBox = 0x000000ffu;
 
 template <int LEVEL, bool WRITE>
-__global__ void __launch_bounds__(kBlock) partition_kernel(LevelArgs a) {
+__global__ void __launch_bounds__(Level<LEVEL>::kThreads) partition_kernel(LevelArgs a) {
   constexpr uint32_t L = Level<LEVEL>::kPiece;
+  constexpr int T = Level<LEVEL>::kThreads;
+  constexpr int kIter = (int)L / T;
   __shared__ uint32_t s_box[L];
-  __shared__ uint32_t s_idx[WRITE ? L : 1];
-  __shared__ uint32_t s_r0[(WRITE && LEVEL == 1) ? L : 1];   // level 1: rectangle min / max words
-  __shared__ uint32_t s_r1[(WRITE && LEVEL == 1) ? L : 1];
+  __shared__ uint32_t s_idx[(WRITE && LEVEL != 1) ? L : 1];
+  __shared__ u64 s_val[(WRITE && LEVEL == 1) ? L : 1];       // level 1 passes the packed word on unchanged
 
-  uint32_t start, len, np, slot0, F, FX;
+  uint32_t parent = 0, start, len, np, slot0, F, FX;
   if (LEVEL == 1) {
     np = (a.V + L - 1) / L;
     if (blockIdx.x >= np) return;
@@ -175,6 +219,7 @@ __global__ void __launch_bounds__(kBlock) partition_kernel(LevelArgs a) {
     const uint4 d = a.desc[blockIdx.x];
     const uint32_t pf0 = a.piece_first[d.x];
     np = a.piece_first[d.x + 1] - pf0;
+    parent = d.x;
     start = d.y;
     len = d.z;
     slot0 = pf0 * kSuper + d.w;
@@ -182,86 +227,97 @@ __global__ void __launch_bounds__(kBlock) partition_kernel(LevelArgs a) {
     FX = kSuper;
   }
 
-  // stage the piece
+  // stage the piece: all global loads of a thread are issued before any is used
   const uint32_t padded = (len + 63u) & ~63u;
-  for (uint32_t i = threadIdx.x; i < padded; i += kBlock) {
-    uint32_t box = kNoBox;
-    if (i < len) {
-      if (LEVEL == 1) {
-        const uint32_t g = a.order[start + i];
-        const uint2 r = a.rects[g];
-        const uint32_t x0 = r.x & 0xffffu, y0 = r.x >> 16, x1 = r.y & 0xffffu, y1 = r.y >> 16;
-        const uint32_t bx0 = x0 / kSuper, bx1 = (x1 - 1) / kSuper, by0 = y0 / kSuper, by1 = (y1 - 1) / kSuper;
-        box = bx0 | ((bx1 - bx0) << 8) | (by0 << 16) | ((by1 - by0) << 24);
-        if (WRITE) { s_idx[i] = g; s_r0[i] = r.x; s_r1[i] = r.y; }
-      } else {
-        const u64 e = a.in[start + i];
-        const uint32_t lb = (uint32_t)(e >> 32);
-        if (LEVEL == 2) {
-          const uint32_t y0 = (lb >> 8) & 15u, y1 = (lb >> 12) & 15u;
-          box = y0 | ((y1 - y0) << 8) | ((lb & 0xffu) << 16);
-        } else {
-          const uint32_t x0 = lb & 15u, x1 = (lb >> 4) & 15u;
-          box = x0 | ((x1 - x0) << 8);
+  {
+    u64 en[kIter];
+#pragma unroll
+    for (int it = 0; it < kIter; it++) {
+      const uint32_t i = it * T + threadIdx.x;
+      en[it] = i < len ? a.in[start + i] : 0ull;
+    }
+    const uint32_t cx = (parent % (uint32_t)a.g.sx) * kSuper, cy = (parent / (uint32_t)a.g.sx) * kSuper;  // level 2
+#pragma unroll
+    for (int it = 0; it < kIter; it++) {
+      const uint32_t i = it * T + threadIdx.x;
+      if (i < padded) {
+        uint32_t box = kNoBox;
+        if (i < len) {
+          if (LEVEL == 1) {
+            uint32_t x0, x1, y0, y1;
+            a.pk.rect(en[it], x0, x1, y0, y1);
+            const uint32_t bx0 = x0 / kSuper, bx1 = x1 / kSuper, by0 = y0 / kSuper, by1 = y1 / kSuper;
+            box = bx0 | ((bx1 - bx0) << 8) | (by0 << 16) | ((by1 - by0) << 24);
+            if (WRITE) s_val[i] = en[it];
+          } else if (LEVEL == 2) {
+            // rectangle clipped to this supercell, in tiles relative to its corner
+            uint32_t x0, x1, y0, y1;
+            a.pk.rect(en[it], x0, x1, y0, y1);
+            const uint32_t lx0 = max(x0, cx) - cx, lx1 = min(x1, cx + kSuper - 1u) - cx;
+            const uint32_t ly0 = max(y0, cy) - cy, ly1 = min(y1, cy + kSuper - 1u) - cy;
+            box = ly0 | ((ly1 - ly0) << 8) | ((lx0 | (lx1 << 4)) << 16);
+            if (WRITE) s_idx[i] = a.pk.index(en[it]);
+          } else {
+            const uint32_t lb = (uint32_t)(en[it] >> 32);
+            const uint32_t x0 = lb & 15u, x1 = (lb >> 4) & 15u;
+            box = x0 | ((x1 - x0) << 8);
+            if (WRITE) s_idx[i] = (uint32_t)en[it];
+          }
         }
-        if (WRITE) s_idx[i] = (uint32_t)e;
+        s_box[i] = box;
       }
     }
-    s_box[i] = box;
   }
   __syncthreads();
 
-  const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
-  const uint32_t per_wave = (F + 3u) / 4u;
+  // the wave index as a scalar: everything per bucket below then lives in scalar registers
+  const uint32_t wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+  const int lane = threadIdx.x & 63;
+  constexpr uint32_t kWaves = T / 64;
+  constexpr int CH = Level<LEVEL>::kChunk;
+  const uint32_t per_wave = (F + kWaves - 1u) / kWaves;
   const uint32_t f_end = min(F, (wave + 1) * per_wave);
-  for (uint32_t fb = wave * per_wave; fb < f_end; fb += 8) {
-    const uint32_t nb = min(8u, f_end - fb);
-    uint32_t run[8], fx[8], fy[8];
+  for (uint32_t fb = wave * per_wave; fb < f_end; fb += CH) {
+    // buckets past f_end get an index no interval reaches: they count nothing and write nothing
+    uint32_t run[CH], fx[CH], fy[CH];
 #pragma unroll
-    for (int j = 0; j < 8; j++) {
+    for (int j = 0; j < CH; j++) {
       const uint32_t f = fb + j;
-      fx[j] = LEVEL == 1 ? f % FX : f;
+      const bool real = f < f_end;
+      fx[j] = real ? (LEVEL == 1 ? f % FX : f) : 0xffffu;
       fy[j] = LEVEL == 1 ? f / FX : 0u;
-      run[j] = 0u;
-      if (WRITE && (uint32_t)j < nb) run[j] = a.counts[slot0 + f * np];
+      run[j] = (WRITE && real) ? a.counts[slot0 + f * np] : 0u;
     }
     for (uint32_t base = 0; base < len; base += 64) {
       const uint32_t w = s_box[base + lane];
       const uint32_t lo = w & 0xffu, wd = (w >> 8) & 0xffu, lo2 = (w >> 16) & 0xffu, wd2 = w >> 24;
-      uint32_t idx = 0u, r0 = 0u, r1 = 0u;
+      uint32_t idx = 0u;
+      u64 val = 0ull;
       if (WRITE) {
-        idx = s_idx[base + lane];
-        if (LEVEL == 1) { r0 = s_r0[base + lane]; r1 = s_r1[base + lane]; }
+        if (LEVEL == 1) val = s_val[base + lane]; else idx = s_idx[base + lane];
       }
 #pragma unroll
-      for (int j = 0; j < 8; j++) {
-        if ((uint32_t)j < nb) {
-          bool hit = (fx[j] - lo) <= wd;
-          if (LEVEL == 1) hit = hit && ((fy[j] - lo2) <= wd2);
-          const unsigned long long bal = __ballot(hit);
-          if (WRITE && hit) {
-            const uint32_t pos = run[j] + lanes_below(bal);
-            if (LEVEL == 1) {
-              // rectangle clipped to the supercell, in tiles relative to its corner, 4 bits each
-              const uint32_t cx = fx[j] * kSuper, cy = fy[j] * kSuper;
-              const uint32_t x0 = r0 & 0xffffu, y0 = r0 >> 16, x1 = (r1 & 0xffffu) - 1u, y1 = (r1 >> 16) - 1u;
-              const uint32_t lx0 = max(x0, cx) - cx, lx1 = min(x1, cx + kSuper - 1u) - cx;
-              const uint32_t ly0 = max(y0, cy) - cy, ly1 = min(y1, cy + kSuper - 1u) - cy;
-              a.out64[pos] = (u64)idx | ((u64)(lx0 | (lx1 << 4) | (ly0 << 8) | (ly1 << 12)) << 32);
-            } else if (LEVEL == 2) {
-              a.out64[pos] = (u64)idx | ((u64)lo2 << 32);
-            } else {
-              a.out32[pos] = idx;
-            }
+      for (int j = 0; j < CH; j++) {
+        bool hit = (fx[j] - lo) <= wd;
+        if (LEVEL == 1) hit = hit && ((fy[j] - lo2) <= wd2);
+        const unsigned long long bal = __ballot(hit);
+        if (WRITE && hit) {
+          const uint32_t pos = run[j] + lanes_below(bal);
+          if (LEVEL == 1) {
+            a.out64[pos] = val;
+          } else if (LEVEL == 2) {
+            a.out64[pos] = (u64)idx | ((u64)lo2 << 32);
+          } else {
+            a.out32[pos] = idx;
           }
-          run[j] += (uint32_t)__popcll(bal);
         }
+        run[j] += (uint32_t)__popcll(bal);
       }
     }
     if (!WRITE && lane == 0) {
 #pragma unroll
-      for (int j = 0; j < 8; j++)
-        if ((uint32_t)j < nb) a.counts[slot0 + (fb + j) * np] = run[j];
+      for (int j = 0; j < CH; j++)
+        if (fb + j < f_end) a.counts[slot0 + (fb + j) * np] = run[j];
     }
   }
 }
@@ -273,18 +329,25 @@ __global__ void __launch_bounds__(kBlock) partition_kernel(LevelArgs a) {
 // gets the total.  a must be 16-byte aligned.
 __device__ uint32_t block_scan_inplace(uint32_t* a, uint32_t n, uint32_t* s_wave /* kScanBlock / 64 words */) {
   const int t = threadIdx.x, lane = t & 63, w = t >> 6;
+  constexpr int kVec = 4;                       // 16-byte loads per thread and round, all in flight together
   uint32_t carry = 0;
-  for (uint32_t base = 0; base < n; base += 4 * kScanBlock) {
-    const uint32_t i = base + 4 * t;
-    uint4 v = make_uint4(0u, 0u, 0u, 0u);
-    if (i + 3 < n) {
-      v = *reinterpret_cast<const uint4*>(a + i);
-    } else {
-      if (i < n) v.x = a[i];
-      if (i + 1 < n) v.y = a[i + 1];
-      if (i + 2 < n) v.z = a[i + 2];
+  for (uint32_t base = 0; base < n; base += 4 * kVec * kScanBlock) {
+    const uint32_t i0 = base + 4 * kVec * t;
+    uint4 v[kVec];
+    uint32_t s = 0;
+#pragma unroll
+    for (int k = 0; k < kVec; k++) {
+      const uint32_t i = i0 + 4 * k;
+      v[k] = make_uint4(0u, 0u, 0u, 0u);
+      if (i + 3 < n) {
+        v[k] = *reinterpret_cast<const uint4*>(a + i);
+      } else {
+        if (i < n) v[k].x = a[i];
+        if (i + 1 < n) v[k].y = a[i + 1];
+        if (i + 2 < n) v[k].z = a[i + 2];
+      }
+      s += v[k].x + v[k].y + v[k].z + v[k].w;
     }
-    const uint32_t s = v.x + v.y + v.z + v.w;
     uint32_t inc = s;
 #pragma unroll
     for (int o = 1; o < 64; o <<= 1) {
@@ -300,14 +363,19 @@ __device__ uint32_t block_scan_inplace(uint32_t* a, uint32_t n, uint32_t* s_wave
       before += k < w ? x : 0u;
       tot += x;
     }
-    const uint32_t ex = carry + before + inc - s;
-    const uint4 o4 = make_uint4(ex, ex + v.x, ex + v.x + v.y, ex + v.x + v.y + v.z);
-    if (i + 3 < n) {
-      *reinterpret_cast<uint4*>(a + i) = o4;
-    } else {
-      if (i < n) a[i] = o4.x;
-      if (i + 1 < n) a[i + 1] = o4.y;
-      if (i + 2 < n) a[i + 2] = o4.z;
+    uint32_t ex = carry + before + inc - s;
+#pragma unroll
+    for (int k = 0; k < kVec; k++) {
+      const uint32_t i = i0 + 4 * k;
+      const uint4 o4 = make_uint4(ex, ex + v[k].x, ex + v[k].x + v[k].y, ex + v[k].x + v[k].y + v[k].z);
+      ex = o4.w + v[k].w;
+      if (i + 3 < n) {
+        *reinterpret_cast<uint4*>(a + i) = o4;
+      } else {
+        if (i < n) a[i] = o4.x;
+        if (i + 1 < n) a[i + 1] = o4.y;
+        if (i + 2 < n) a[i + 2] = o4.z;
+      }
     }
     carry += tot;
     __syncthreads();
@@ -433,7 +501,7 @@ using DepthSortConfig =
 size_t depth_sort_temp_bytes(int P) {
   size_t bytes = 0;
   (void)rocprim::radix_sort_pairs<DepthSortConfig>(nullptr, bytes, (const uint32_t*)nullptr, (uint32_t*)nullptr,
-                                  rocprim::counting_iterator<uint32_t>(0), (uint32_t*)nullptr, (size_t)P, 0, 32);
+                                  (const u64*)nullptr, (u64*)nullptr, (size_t)P, 0, 32);
   return bytes;
 }
 
@@ -470,14 +538,20 @@ ListsLayout lists_layout(uint32_t V, uint32_t E1, uint32_t E2, const Grid& g) {
 
 }  // namespace
 
-extern "C" int gsr_bin_totals(int P, const uint32_t* rects, uint32_t* totals, void* stream) {
-  GSR_REQUIRE(P >= 0, "bin_totals: bad P");
-  GSR_REQUIRE(totals && (P == 0 || rects), "bin_totals: null pointer");
+extern "C" int gsr_bin_totals(int P, int W, int H, const uint32_t* rects, uint32_t* totals, uint64_t* sort_vals,
+                              void* stream) {
+  GSR_REQUIRE(P >= 0 && W > 0 && H > 0, "bin_totals: bad sizes");
+  GSR_REQUIRE(totals && (P == 0 || (rects && sort_vals)), "bin_totals: null pointer");
   GSR_REQUIRE(((uintptr_t)totals & 15) == 0, "bin_totals: totals must be 16-byte aligned");
+  const Grid g = make_grid(W, H);
+  const Pack pk = make_pack(P, g);
+  GSR_REQUIRE(pk.bits() <= 64, "bin_totals: %d Gaussians on a %dx%d tile grid do not fit the 64-bit sort value", P,
+              g.gx, g.gy);
   hipStream_t st = (hipStream_t)stream;
   const int blocks = P == 0 ? 0 : (gsr::div_up(P, kBlock) < kTotalsBlocks ? gsr::div_up(P, kBlock) : kTotalsBlocks);
   if (blocks)
-    hipLaunchKernelGGL(totals_partial_kernel, dim3(blocks), dim3(kBlock), 0, st, P, (const uint2*)rects, totals + 4);
+    hipLaunchKernelGGL(totals_partial_kernel, dim3(blocks), dim3(kBlock), 0, st, P, pk, (const uint2*)rects,
+                       totals + 4, (u64*)sort_vals);
   hipLaunchKernelGGL(totals_final_kernel, dim3(1), dim3(kBlock), 0, st, blocks, totals + 4, totals);
   return gsr::check_launch("bin_totals");
 }
@@ -487,11 +561,11 @@ extern "C" size_t gsr_bin_sort_bytes(int P) {
   return gsr::align_up((size_t)P * 4, 256) + gsr::align_up(depth_sort_temp_bytes(P), 256) + 256;
 }
 
-extern "C" int gsr_bin_sort(int P, const uint32_t* depth_keys, uint32_t* order, void* scratch, size_t scratch_bytes,
-                            void* stream) {
+extern "C" int gsr_bin_sort(int P, const uint32_t* depth_keys, const uint64_t* sort_vals, uint64_t* sorted_vals,
+                            void* scratch, size_t scratch_bytes, void* stream) {
   GSR_REQUIRE(P >= 0, "bin_sort: bad P");
   if (P == 0) return GSR_OK;
-  GSR_REQUIRE(depth_keys && order && scratch, "bin_sort: null pointer");
+  GSR_REQUIRE(depth_keys && sort_vals && sorted_vals && scratch, "bin_sort: null pointer");
   if (scratch_bytes < gsr_bin_sort_bytes(P) || ((uintptr_t)scratch & 255))
     return gsr::fail(GSR_E_SCRATCH, "bin_sort: scratch too small (%zu < %zu) or not 256-byte aligned", scratch_bytes,
                      gsr_bin_sort_bytes(P));
@@ -501,7 +575,7 @@ extern "C" int gsr_bin_sort(int P, const uint32_t* depth_keys, uint32_t* order, 
   void* temp = base + keys_bytes;
   size_t temp_bytes = scratch_bytes - keys_bytes;
   hipError_t e = rocprim::radix_sort_pairs<DepthSortConfig>(temp, temp_bytes, depth_keys, keys_sorted,
-                                           rocprim::counting_iterator<uint32_t>(0), order, (size_t)P, 0, 32,
+                                           (const u64*)sort_vals, (u64*)sorted_vals, (size_t)P, 0, 32,
                                            (hipStream_t)stream);
   if (e != hipSuccess) return gsr::fail(GSR_E_LAUNCH, "bin_sort: depth sort: %s", hipGetErrorString(e));
   return gsr::check_launch("bin_sort");
@@ -513,7 +587,7 @@ extern "C" size_t gsr_bin_lists_bytes(uint32_t V, uint32_t E1, uint32_t E2, int 
 }
 
 extern "C" int gsr_bin_lists(int P, uint32_t V, uint32_t N, uint32_t E1, uint32_t E2, int W, int H,
-                             const uint32_t* rects, const uint32_t* order, uint32_t* point_list, uint32_t* ranges,
+                             const uint64_t* sorted_vals, uint32_t* point_list, uint32_t* ranges,
                              uint32_t* tile_ids_sorted, void* scratch, size_t scratch_bytes, void* stream) {
   GSR_REQUIRE(P >= 0 && W > 0 && H > 0, "bin_lists: bad sizes");
   GSR_REQUIRE(ranges, "bin_lists: null ranges");
@@ -525,7 +599,7 @@ extern "C" int gsr_bin_lists(int P, uint32_t V, uint32_t N, uint32_t E1, uint32_
                        (size_t)2 * g.tiles());
     return gsr::check_launch("bin_lists");
   }
-  GSR_REQUIRE(rects && order && point_list && scratch, "bin_lists: null pointer");
+  GSR_REQUIRE(sorted_vals && point_list && scratch, "bin_lists: null pointer");
   GSR_REQUIRE(V <= (uint32_t)P && E1 >= V && E2 >= E1 && N >= E2, "bin_lists: inconsistent totals V=%u E1=%u E2=%u N=%u",
               V, E1, E2, N);
   const ListsLayout L = lists_layout(V, E1, E2, g);
@@ -535,17 +609,18 @@ extern "C" int gsr_bin_lists(int P, uint32_t V, uint32_t N, uint32_t E1, uint32_
   char* base = (char*)scratch;
   LevelArgs a{};
   a.g = g;
+  a.pk = make_pack(P, g);
+  GSR_REQUIRE(a.pk.bits() <= 64, "bin_lists: sizes do not fit the 64-bit sort value");
   a.V = V;
 
   // level 1: depth-sorted Gaussians -> supercell lists
-  a.order = order;
-  a.rects = (const uint2*)rects;
+  a.in = (const u64*)sorted_vals;
   a.counts = (uint32_t*)(base + L.counts1);
   a.out64 = (u64*)(base + L.entries1);
-  hipLaunchKernelGGL((partition_kernel<1, false>), dim3(L.pieces1), dim3(kBlock), 0, st, a);
+  hipLaunchKernelGGL((partition_kernel<1, false>), dim3(L.pieces1), dim3(Level<1>::kThreads), 0, st, a);
   hipLaunchKernelGGL(scan1_kernel, dim3(1), dim3(kScanBlock), 0, st, g, V, a.counts, (uint32_t*)(base + L.list_start2),
                      (uint32_t*)(base + L.list_len2), (uint32_t*)(base + L.piece_first2), (uint4*)(base + L.desc2));
-  hipLaunchKernelGGL((partition_kernel<1, true>), dim3(L.pieces1), dim3(kBlock), 0, st, a);
+  hipLaunchKernelGGL((partition_kernel<1, true>), dim3(L.pieces1), dim3(Level<1>::kThreads), 0, st, a);
   int rc = gsr::check_launch("bin_lists: level 1");
   if (rc) return rc;
 
@@ -555,11 +630,11 @@ extern "C" int gsr_bin_lists(int P, uint32_t V, uint32_t N, uint32_t E1, uint32_
   a.desc = (const uint4*)(base + L.desc2);
   a.counts = (uint32_t*)(base + L.counts2);
   a.out64 = (u64*)(base + L.entries2);
-  hipLaunchKernelGGL((partition_kernel<2, false>), dim3(L.max_pieces2), dim3(kBlock), 0, st, a);
+  hipLaunchKernelGGL((partition_kernel<2, false>), dim3(L.max_pieces2), dim3(Level<2>::kThreads), 0, st, a);
   hipLaunchKernelGGL(scan2_kernel, dim3(1), dim3(kScanBlock), 0, st, g, a.piece_first, a.counts,
                      (uint32_t*)(base + L.list_start3), (uint32_t*)(base + L.list_len3),
                      (uint32_t*)(base + L.piece_first3), (uint4*)(base + L.desc3));
-  hipLaunchKernelGGL((partition_kernel<2, true>), dim3(L.max_pieces2), dim3(kBlock), 0, st, a);
+  hipLaunchKernelGGL((partition_kernel<2, true>), dim3(L.max_pieces2), dim3(Level<2>::kThreads), 0, st, a);
   rc = gsr::check_launch("bin_lists: level 2");
   if (rc) return rc;
 
@@ -570,9 +645,9 @@ extern "C" int gsr_bin_lists(int P, uint32_t V, uint32_t N, uint32_t E1, uint32_
   a.counts = (uint32_t*)(base + L.counts3);
   a.out64 = nullptr;
   a.out32 = point_list;
-  hipLaunchKernelGGL((partition_kernel<3, false>), dim3(L.max_pieces3), dim3(kBlock), 0, st, a);
+  hipLaunchKernelGGL((partition_kernel<3, false>), dim3(L.max_pieces3), dim3(Level<3>::kThreads), 0, st, a);
   hipLaunchKernelGGL(scan3_kernel, dim3(1), dim3(kScanBlock), 0, st, g, a.piece_first, a.counts, ranges);
-  hipLaunchKernelGGL((partition_kernel<3, true>), dim3(L.max_pieces3), dim3(kBlock), 0, st, a);
+  hipLaunchKernelGGL((partition_kernel<3, true>), dim3(L.max_pieces3), dim3(Level<3>::kThreads), 0, st, a);
   if (tile_ids_sorted)
     hipLaunchKernelGGL(fill_tile_ids_kernel, dim3(g.tiles()), dim3(kBlock), 0, st, ranges, tile_ids_sorted);
   return gsr::check_launch("bin_lists: level 3");

@@ -52,9 +52,9 @@ def _load():
                                        vp, vp, vp, vp, vp, vp]
     lib.gsr_mark_visible.argtypes = [ci, vp, vp, vp, vp]
     u32 = C.c_uint32
-    lib.gsr_bin_totals.argtypes = [ci, vp, vp, vp]
-    lib.gsr_bin_sort.argtypes = [ci, vp, vp, vp, C.c_size_t, vp]
-    lib.gsr_bin_lists.argtypes = [ci, u32, u32, u32, u32, ci, ci, vp, vp, vp, vp, vp, vp, C.c_size_t, vp]
+    lib.gsr_bin_totals.argtypes = [ci, ci, ci, vp, vp, vp, vp]
+    lib.gsr_bin_sort.argtypes = [ci, vp, vp, vp, vp, C.c_size_t, vp]
+    lib.gsr_bin_lists.argtypes = [ci, u32, u32, u32, u32, ci, ci, vp, vp, vp, vp, vp, C.c_size_t, vp]
     lib.gsr_blend_fwd.argtypes = [ci, ci, vp, vp, vp, vp, vp, vp, vp, vp]
     lib.gsr_blend_bwd.argtypes = [ci, ci, vp, vp, vp, vp, vp, vp, vp, vp, vp]
     lib.gsr_preprocess_bwd.argtypes = [ci, ci, ci, vp, vp, cf, vp, vp, vp, vp, vp, vp, ci, ci, cf, cf, vp, vp,
@@ -160,7 +160,7 @@ class GaussianRasterizationSettings(NamedTuple):
 class ForwardState:
     """Everything the forward leaves behind: op outputs, what backward needs,
     and the intermediate buffers the parity tests inspect."""
-    __slots__ = ("P", "M", "D", "W", "H", "records", "radii", "tiles_touched", "depth_keys", "order", "rect_words",
+    __slots__ = ("P", "M", "D", "W", "H", "records", "radii", "tiles_touched", "depth_keys", "sorted_vals", "rect_words",
                  "num_rendered", "num_visible", "point_list", "ranges", "tile_ids_sorted", "color", "final_T", "n_contrib",
                  "view", "proj", "campos", "bg")
 
@@ -222,7 +222,7 @@ def rasterize_forward(s: GaussianRasterizationSettings, means3D, opacities, shs=
     st.radii = torch.empty((P,), **u32)
     st.tiles_touched = torch.empty((P,), **u32)
     st.depth_keys = torch.empty((P,), **u32)
-    st.order = torch.empty((P,), **u32)
+    st.sorted_vals = torch.empty((P,), dtype=torch.int64, device=dev)   # packed (index, rectangle), front to back
     st.rect_words = torch.empty((P, 2), **u32)
     gx, gy = (W + TILE - 1) // TILE, (H + TILE - 1) // TILE
     st.ranges = torch.empty((gx * gy, 2), **u32)
@@ -251,14 +251,16 @@ def rasterize_forward(s: GaussianRasterizationSettings, means3D, opacities, shs=
         # The list sizes go to the host (the pipeline's one read-back) while the GPU sorts by depth:
         # the copy is queued before the sort and the host waits for the copy alone.
         totals = torch.empty((TOTALS_WORDS,), **u32)
-        _run("bin_totals", _lib.gsr_bin_totals, P, _ptr(st.rect_words), _ptr(totals), stream)
+        sort_vals = torch.empty((P,), dtype=torch.int64, device=dev)
+        _run("bin_totals", _lib.gsr_bin_totals, P, W, H, _ptr(st.rect_words), _ptr(totals), _ptr(sort_vals), stream)
         host = _pinned_totals(dev)
         host.copy_(totals[:4], non_blocking=True)
         copied = torch.cuda.Event()
         copied.record()
         nb = _lib.gsr_bin_sort_bytes(P)
         scratch = torch.empty((nb,), dtype=torch.uint8, device=dev)
-        _run("bin_sort", _lib.gsr_bin_sort, P, _ptr(st.depth_keys), _ptr(st.order), _ptr(scratch), nb, stream)
+        _run("bin_sort", _lib.gsr_bin_sort, P, _ptr(st.depth_keys), _ptr(sort_vals), _ptr(st.sorted_vals),
+             _ptr(scratch), nb, stream)
         copied.synchronize()
         N, E1, E2, V = (int(v) & 0xFFFFFFFF for v in host.tolist())
     st.num_rendered, st.num_visible = N, V
@@ -267,8 +269,8 @@ def rasterize_forward(s: GaussianRasterizationSettings, means3D, opacities, shs=
         st.tile_ids_sorted = torch.empty((max(N, 1),), **u32)
     nb = _lib.gsr_bin_lists_bytes(V, E1, E2, W, H)
     scratch = torch.empty((nb,), dtype=torch.uint8, device=dev)
-    _run("bin_lists", _lib.gsr_bin_lists, P, V, N, E1, E2, W, H, _ptr(st.rect_words), _ptr(st.order),
-         _ptr(st.point_list), _ptr(st.ranges), _ptr(st.tile_ids_sorted), _ptr(scratch), nb, stream)
+    _run("bin_lists", _lib.gsr_bin_lists, P, V, N, E1, E2, W, H, _ptr(st.sorted_vals), _ptr(st.point_list),
+         _ptr(st.ranges), _ptr(st.tile_ids_sorted), _ptr(scratch), nb, stream)
     _run("blend_fwd", _lib.gsr_blend_fwd, W, H, _ptr(st.ranges), _ptr(st.point_list), _ptr(st.records), _ptr(st.bg),
                               _ptr(st.color), _ptr(st.final_T), _ptr(st.n_contrib), stream)
     st.point_list = st.point_list[:N]

@@ -111,19 +111,26 @@ int gsr_mark_visible(int P, const float* means3D, const float* viewmatrix, uint8
  * tiles), by CELL (tile row x strip of 16 tiles) and by tile.  Every step is
  * stable, so the lists equal the 64-bit sort's.
  *
+ * No index is ever dereferenced on the way: the depth sort carries, as its
+ * 64-bit value, the Gaussian's index packed with its tile rectangle (bit
+ * widths chosen from P and the tile grid; gsr_bin_totals fails if they exceed
+ * 64 bits, e.g. more than 2^24 Gaussians on a grid of more than 1024x1024 tiles).
+ *
  * gsr_bin_totals: totals[0..3] = { N = tile instances (sum of tiles_touched),
  * E1 = supercell entries, E2 = cell entries, V = visible Gaussians }, from the
- * rectangles alone.  The caller reads the four words back (the pipeline's one
- * host read-back; it can overlap gsr_bin_sort) to size gsr_bin_lists.  totals
- * has GSR_TOTALS_WORDS words (the rest is the call's scratch), 16-byte aligned. */
+ * rectangles alone, and sort_vals (P) uint64 = the packed (index, rectangle)
+ * words.  The caller reads the four totals back (the pipeline's one host
+ * read-back; it can overlap gsr_bin_sort) to size gsr_bin_lists.  totals has
+ * GSR_TOTALS_WORDS words (the rest is the call's scratch), 16-byte aligned. */
 #define GSR_TOTALS_WORDS (4 + 4 * 256)
-int gsr_bin_totals(int P, const uint32_t* rects, uint32_t* totals, void* stream);
+int gsr_bin_totals(int P, int W, int H, const uint32_t* rects, uint32_t* totals,
+                   uint64_t* sort_vals, void* stream);
 
-/* gsr_bin_sort: order (P) uint32 = Gaussian indices by ascending depth key,
- * ties by ascending index; the V visible ones come first. */
+/* gsr_bin_sort: sorted_vals (P) uint64 = sort_vals ordered by ascending depth
+ * key, ties by ascending index (stable); the V visible ones come first. */
 size_t gsr_bin_sort_bytes(int P);
-int gsr_bin_sort(int P, const uint32_t* depth_keys, uint32_t* order, void* scratch,
-                 size_t scratch_bytes, void* stream);
+int gsr_bin_sort(int P, const uint32_t* depth_keys, const uint64_t* sort_vals,
+                 uint64_t* sorted_vals, void* scratch, size_t scratch_bytes, void* stream);
 
 /* gsr_bin_lists: point_list (N) uint32 = Gaussian index per sorted instance;
  * ranges (tiles,2) uint32 = [start,end) into point_list per tile, (0,0) for
@@ -133,9 +140,9 @@ int gsr_bin_sort(int P, const uint32_t* depth_keys, uint32_t* order, void* scrat
  * (tile << 32) | depth_key[point_list]. */
 size_t gsr_bin_lists_bytes(uint32_t V, uint32_t E1, uint32_t E2, int W, int H);
 int gsr_bin_lists(int P, uint32_t V, uint32_t N, uint32_t E1, uint32_t E2, int W, int H,
-                  const uint32_t* rects, const uint32_t* order, uint32_t* point_list,
-                  uint32_t* ranges, uint32_t* tile_ids_sorted, void* scratch,
-                  size_t scratch_bytes, void* stream);
+                  const uint64_t* sorted_vals, uint32_t* point_list, uint32_t* ranges,
+                  uint32_t* tile_ids_sorted, void* scratch, size_t scratch_bytes,
+                  void* stream);
 
 /* ---- Stage 3: blend forward ----------------------------------------------
  * Front-to-back alpha compositing per tile (the module's per-tile render
