@@ -288,6 +288,7 @@ __global__ void __launch_bounds__(Level<LEVEL>::kThreads) partition_kernel(Level
       fy[j] = LEVEL == 1 ? f / FX : 0u;
       run[j] = (WRITE && real) ? a.counts[slot0 + f * np] : 0u;
     }
+#pragma unroll 4
     for (uint32_t base = 0; base < len; base += 64) {
       const uint32_t w = s_box[base + lane];
       const uint32_t lo = w & 0xffu, wd = (w >> 8) & 0xffu, lo2 = (w >> 16) & 0xffu, wd2 = w >> 24;
@@ -395,14 +396,22 @@ __device__ __forceinline__ uint32_t owner_of(const uint32_t* first, uint32_t n, 
 
 // Cuts the lists (list_start, list_len)[0..n) into pieces of at most piece_len entries:
 // piece_first (n + 1 words, holds the piece counts on entry) and the descriptors.
+constexpr uint32_t kFirstLds = 4096;    // piece_first is searched from LDS when it has at most this many words
+
 __device__ void build_pieces(uint32_t n, const uint32_t* list_start, const uint32_t* list_len, uint32_t piece_len,
-                             uint32_t* piece_first, uint4* desc, uint32_t* s_wave) {
+                             uint32_t* piece_first, uint4* desc, uint32_t* s_wave, uint32_t* s_first) {
   __syncthreads();
   const uint32_t pieces = block_scan_inplace(piece_first, n + 1, s_wave);
   __syncthreads();
+  const uint32_t* first = piece_first;
+  if (n + 1 <= kFirstLds) {
+    for (uint32_t b = threadIdx.x; b <= n; b += kScanBlock) s_first[b] = piece_first[b];
+    __syncthreads();
+    first = s_first;
+  }
   for (uint32_t q = threadIdx.x; q < pieces; q += kScanBlock) {
-    const uint32_t b = owner_of(piece_first, n, q);
-    const uint32_t j = q - piece_first[b];
+    const uint32_t b = owner_of(first, n, q);
+    const uint32_t j = q - first[b];
     const uint32_t len = list_len[b];
     desc[q] = make_uint4(b, list_start[b] + j * piece_len, min(piece_len, len - j * piece_len), j);
   }
@@ -412,6 +421,7 @@ __device__ void build_pieces(uint32_t n, const uint32_t* list_start, const uint3
 __global__ void __launch_bounds__(kScanBlock) scan1_kernel(Grid g, uint32_t V, uint32_t* counts, uint32_t* list_start,
                                                            uint32_t* list_len, uint32_t* piece_first, uint4* desc) {
   __shared__ uint32_t s_wave[kScanBlock / 64];
+  __shared__ uint32_t s_first[kFirstLds];
   const uint32_t F = (uint32_t)g.supercells(), np = (V + kPiece1 - 1) / kPiece1, slots = np * F;
   const uint32_t total = block_scan_inplace(counts, slots, s_wave);
   __syncthreads();
@@ -423,7 +433,7 @@ __global__ void __launch_bounds__(kScanBlock) scan1_kernel(Grid g, uint32_t V, u
     piece_first[b] = (end - begin + kPiece2 - 1) / kPiece2;
   }
   if (threadIdx.x == 0) piece_first[F] = 0u;
-  build_pieces(F, list_start, list_len, kPiece2, piece_first, desc, s_wave);
+  build_pieces(F, list_start, list_len, kPiece2, piece_first, desc, s_wave, s_first);
 }
 
 // After the level-2 counting sweep: positions, the cell lists (row-major cell ids), the level-3 pieces.
@@ -431,6 +441,7 @@ __global__ void __launch_bounds__(kScanBlock) scan2_kernel(Grid g, const uint32_
                                                            uint32_t* list_start, uint32_t* list_len,
                                                            uint32_t* piece_first, uint4* desc) {
   __shared__ uint32_t s_wave[kScanBlock / 64];
+  __shared__ uint32_t s_first[kFirstLds];
   const uint32_t parents = (uint32_t)g.supercells();
   const uint32_t slots = piece_first2[parents] * kSuper;
   const uint32_t total = block_scan_inplace(counts, slots, s_wave);
@@ -452,7 +463,7 @@ __global__ void __launch_bounds__(kScanBlock) scan2_kernel(Grid g, const uint32_
     piece_first[cell] = (end - begin + kPiece3 - 1) / kPiece3;
   }
   if (threadIdx.x == 0) piece_first[g.cells()] = 0u;
-  build_pieces((uint32_t)g.cells(), list_start, list_len, kPiece3, piece_first, desc, s_wave);
+  build_pieces((uint32_t)g.cells(), list_start, list_len, kPiece3, piece_first, desc, s_wave, s_first);
 }
 
 // After the level-3 counting sweep: positions in point_list and the tile ranges,
