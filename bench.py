@@ -64,6 +64,29 @@ def algorithmic_bytes(P, N, W, H, M=16):
     }
 
 
+def published_binning_bytes(P, V, N, W, H):
+    """Bytes the published binning chain moves for the same lists: prefix sum 8 P, key/value
+    duplication 12 N + 8 V, 64-bit (tile | depth) radix sort 24 N per 8-bit pass over
+    32 + ceil(log2 tiles) key bits, range identification 8 N + 8 tiles.  The binning here
+    produces the identical lists without sorting instances, so it moves far fewer bytes;
+    this figure only prices its time against that chain."""
+    tiles = ((W + 15) // 16) * ((H + 15) // 16)
+    key_bits = 32 + max(1, math.ceil(math.log2(tiles)))
+    return 8 * P + 12 * N + 8 * V + 24 * N * math.ceil(key_bits / 8) + 8 * N + 8 * tiles
+
+
+def measured_traffic(workload):
+    """HBM bytes per launch from the committed rocprofv3 counter runs (FETCH_SIZE / WRITE_SIZE
+    passes, corrected as profiles/r01_traffic.json says), or {} when none exists for this workload."""
+    path = os.path.join(ROOT, "profiles", "r01_traffic.json")
+    try:
+        with open(path) as f:
+            t = json.load(f)
+        return t["bytes_per_launch"] if t.get("workload") == workload else {}
+    except (OSError, ValueError, KeyError):
+        return {}
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -165,6 +188,11 @@ def main():
         kernels = {k: {"ms": round(stage_ms[k], 4), "algorithmic_GB": round(alg[k] / 1e9, 4) if k in alg else None,
                        "GBps": round(alg[k] / (stage_ms[k] * 1e-3) / 1e9, 1) if k in alg else None}
                    for k in stage_ms}
+        bin_ms = sum(stage_ms.get(k, 0.0) for k in ("bin_totals", "bin_sort", "bin_lists"))
+        pub = published_binning_bytes(P, N, st_N, W, H)
+        kernels["binning_total"] = {"ms": round(bin_ms, 4), "published_chain_GB": round(pub / 1e9, 4),
+                                    "GBps_vs_published_chain": round(pub / (bin_ms * 1e-3) / 1e9, 1)}
+        traffic = measured_traffic(args.workload).get(dominant)
         line = {
             "metric": "train-step ms + render Msplats/s @1080p, 1M Gaussians, 1/2/4/8 MI355X",
             "value": round(msplats, 2), "unit": "Msplats/s", "n_gpus": world, "steps": args.steps,
@@ -172,10 +200,13 @@ def main():
             "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
             "config": {"workload": f"{args.workload}: {P} Gaussians, {W}x{H}, SH degree {deg}, full train step "
                                    "(activations + render + 0.8*L1+0.2*(1-SSIM) + backward), one view per GPU",
-                       "gaussians": P, "visible": N, "tile_instances": st_N, "views_per_step": world},
+                       "gaussians": P, "visible": N, "tile_instances": st_N, "views_per_step": world,
+                       "activations": "torch ops (as the reference)" if args.unfused else "in the preprocess kernels"},
             "train_step_ms": round(ms_per_step, 3), "render_ms": round(render_ms, 3),
             "roofline": {"bound": "hbm", "kernel": dominant, "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS,
-                         "unit": "GB/s", "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": None},
+                         "unit": "GB/s", "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": traffic,
+                         "traffic_unit": "bytes/launch (rocprofv3 FETCH_SIZE x2 + WRITE_SIZE, profiles/r01_traffic.json)",
+                         "algorithmic_bytes": alg[dominant]},
             "kernels": kernels,
         }
         if world == 1 and not args.no_cpu_baseline:
@@ -217,11 +248,14 @@ def cpu_baseline(cloud, W, H, deg):
                         cam.camera_center.numpy())
     arrs = dict(means3D=cloud.xyz.numpy(), opacities=cloud.opacity.numpy(), scales=cloud.scaling.numpy(),
                 rotations=cloud.rotation.numpy(), shs=cloud.features.numpy())
-    t0 = time.perf_counter()
-    o.forward(s, want_margin=False, **arrs)
-    dt = time.perf_counter() - t0
+    o.forward(s, want_margin=False, **arrs)                 # warm-up: page faults, thread pool
+    reps, t0 = 0, time.perf_counter()
+    while reps < 3 or time.perf_counter() - t0 < 10.0:
+        o.forward(s, want_margin=False, **arrs)
+        reps += 1
+    dt = (time.perf_counter() - t0) / reps
     return {"value": round(cloud.count / dt / 1e6, 4), "unit": "Msplats/s", "cores": threads, "kind": "port",
-            "sample": f"1 forward render (preprocess + binning + blend) of the full workload, {dt:.2f} s; "
+            "sample": f"{reps} forward renders (preprocess + binning + blend) of the full workload, {dt:.2f} s each; "
                       "blend and preprocess run on all cores (OpenMP), the sort on one"}
 
 
