@@ -96,6 +96,9 @@ def main():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--unfused", action="store_true",
                     help="apply the model's activations with PyTorch ops, as the reference does, instead of in-kernel")
+    ap.add_argument("--dp-grads", action="store_true",
+                    help="data-parallel training: all-reduce the gradients of all ranks (one flat buffer, RCCL) "
+                         "inside the timed step, instead of the scalar loss only")
     args = ap.parse_args()
 
     world = int(os.environ.get("WORLD_SIZE", "1"))
@@ -128,6 +131,9 @@ def main():
     pipe = PipelineParams(fused_activations=not args.unfused)
     params = [p for p in model.parameters()]
 
+    from gsplat_host.optim import GaussianAdam, all_reduce_gradients
+    opt = GaussianAdam.for_model(model)
+
     timer = dgr.StageTimer()
     fwd_events = []
 
@@ -147,7 +153,10 @@ def main():
             lv = loss.detach().clone()
             dist.all_reduce(lv)                                       # RCCL over xGMI: one fp32 scalar
             lv /= world
+        if args.dp_grads:
+            step.grad_scale = all_reduce_gradients(opt.params)        # RCCL over xGMI: 59 floats per Gaussian
         return out
+    step.grad_scale = 1.0
 
     def barrier():
         torch.cuda.synchronize()
@@ -177,6 +186,19 @@ def main():
         render_ms = float(t.item())
     ms_per_step = 1e3 * elapsed / args.steps
     msplats = world * P / (render_ms * 1e-3) / 1e6
+
+    # the optimiser step sits outside the reference's timed span (train.py:95 precedes :126-128):
+    # timed on its own, after the step loop, on the last step's gradients
+    adam_events = []
+    for _ in range(5):
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record()
+        opt.step(grad_scale=step.grad_scale)
+        e1.record()
+        adam_events.append((e0, e1))
+    torch.cuda.synchronize()
+    adam_ms = sorted(a.elapsed_time(b) for a, b in adam_events)[len(adam_events) // 2]
+    n_params = sum(p.numel() for p in params)
 
     if rank == 0:
         stage_ms = timer.mean_ms()
@@ -208,6 +230,11 @@ def main():
                          "traffic_unit": "bytes/launch (rocprofv3 FETCH_SIZE x2 + WRITE_SIZE, profiles/r01_traffic.json)",
                          "algorithmic_bytes": alg[dominant]},
             "kernels": kernels,
+            "optimizer": {"what": "fused Adam over the six parameter tensors, outside the timed step as in the reference",
+                          "ms": round(adam_ms, 4), "parameters": n_params,
+                          "GBps": round(28 * n_params / (adam_ms * 1e-3) / 1e9, 1)},
+            "gradient_exchange": "all-reduce of all gradients inside the timed step" if args.dp_grads
+                                 else "none (scalar loss only)",
         }
         if world == 1 and not args.no_cpu_baseline:
             line["cpu_baseline"] = cpu_baseline(cloud, W, H, deg)

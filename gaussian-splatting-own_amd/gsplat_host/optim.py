@@ -1,0 +1,195 @@
+"""Optimiser step and data-parallel gradient exchange of the reference's training loop.
+
+The reference steps ``torch.optim.Adam`` over six parameter tensors with one
+learning rate each and ``eps = 1e-15`` (``scene/gaussian_model.py:154-163``,
+``train.py:126-128``) and decays the position learning rate log-linearly
+(``:164-175``, ``utils/general_utils.py:29-62``).  Here the update of all six
+tensors is ONE fused HIP launch (``gsr_adam_step``), and, when several ranks
+each render their own view of a replicated model, their gradients meet in one
+flat buffer that is all-reduced once over RCCL before the step.  There is no
+CPU path for the update: the parameters must live on the GPU.
+"""
+from __future__ import annotations
+
+import ctypes as C
+import math
+from dataclasses import dataclass
+from typing import Dict, List, Optional
+
+import torch
+import torch.distributed as dist
+
+import diff_gaussian_rasterization as _dgr
+
+_lib = _dgr._lib
+MAX_TENSORS = 8
+
+
+class _AdamTensor(C.Structure):
+    _fields_ = [("param", C.c_void_p), ("grad", C.c_void_p), ("exp_avg", C.c_void_p), ("exp_avg_sq", C.c_void_p),
+                ("n", C.c_size_t), ("lr", C.c_float), ("vec4", C.c_int)]
+
+
+_lib.gsr_adam_step.argtypes = [C.c_int, C.POINTER(_AdamTensor), C.c_double, C.c_double, C.c_double, C.c_int, C.c_float,
+                               C.c_void_p]
+
+
+def expon_lr(step: int, lr_init: float, lr_final: float, lr_delay_steps: int = 0, lr_delay_mult: float = 1.0,
+             max_steps: int = 1_000_000) -> float:
+    """Log-linear learning-rate decay with an optional eased-in start (utils/general_utils.py:29-62)."""
+    if step < 0 or (lr_init == 0.0 and lr_final == 0.0):
+        return 0.0
+    if lr_delay_steps > 0:
+        delay = lr_delay_mult + (1 - lr_delay_mult) * math.sin(0.5 * math.pi * min(max(step / lr_delay_steps, 0), 1))
+    else:
+        delay = 1.0
+    t = min(max(step / max_steps, 0), 1)
+    return delay * math.exp(math.log(lr_init) * (1 - t) + math.log(lr_final) * t)
+
+
+@dataclass
+class OptimizationParams:
+    """The optimiser-related fields of arguments/__init__.py:71-90."""
+    position_lr_init: float = 0.00016
+    position_lr_final: float = 0.0000016
+    position_lr_delay_mult: float = 0.01
+    position_lr_max_steps: int = 30_000
+    feature_lr: float = 0.0025
+    opacity_lr: float = 0.05
+    scaling_lr: float = 0.005
+    rotation_lr: float = 0.001
+
+
+class GradArena:
+    """One flat fp32 buffer holding the gradients of all parameter tensors back to back (each
+    start 16-byte aligned), with a view per tensor.  Backward passes write into the views, the
+    data-parallel exchange is a single all-reduce of ``flat``, and the optimiser reads the views."""
+
+    def __init__(self, params: Dict[str, torch.Tensor]):
+        self.offsets, total = {}, 0
+        for name, p in params.items():
+            self.offsets[name] = total
+            total += (p.numel() + 3) // 4 * 4
+        first = next(iter(params.values()))
+        self.flat = torch.zeros((total,), dtype=torch.float32, device=first.device)
+        self.views = {name: self.flat[o:o + params[name].numel()].view_as(params[name])
+                      for name, o in self.offsets.items()}
+
+    def attach(self, params: Dict[str, torch.Tensor]) -> None:
+        """Makes every parameter's ``.grad`` the arena view, so autograd accumulates in place."""
+        for name, p in params.items():
+            p.grad = self.views[name]
+
+    def zero_(self) -> None:
+        self.flat.zero_()
+
+    def all_reduce(self, group=None) -> float:
+        """Sums the gradients over the ranks of ``group`` in one collective; returns the factor
+        (1 / world size) that turns the sum into the mean, to be applied by the optimiser step.
+        Without an initialised process group this is a no-op with factor 1."""
+        if not (dist.is_available() and dist.is_initialized()):
+            return 1.0
+        world = dist.get_world_size(group)
+        if world > 1:
+            if dist.get_backend(group) == "gloo" and self.flat.is_cuda:
+                host = self.flat.cpu()                      # gloo only ever sees host tensors
+                dist.all_reduce(host, op=dist.ReduceOp.SUM, group=group)
+                self.flat.copy_(host)
+            else:
+                dist.all_reduce(self.flat, op=dist.ReduceOp.SUM, group=group)
+        return 1.0 / world
+
+
+def all_reduce_gradients(params: Dict[str, torch.Tensor], group=None) -> float:
+    """Sums ``param.grad`` of every tensor over the ranks, all collectives in flight together
+    (the 45-coefficient SH gradient is 3/4 of the bytes; coalescing the small ones buys nothing
+    next to it), and returns 1 / world size for the optimiser step to apply.  For gradients
+    that already sit in a GradArena use its single-collective ``all_reduce`` instead."""
+    if not (dist.is_available() and dist.is_initialized()):
+        return 1.0
+    world = dist.get_world_size(group)
+    if world > 1:
+        host_side = dist.get_backend(group) == "gloo"
+        pending = []
+        for p in params.values():
+            if p.grad is None:
+                continue
+            if host_side and p.grad.is_cuda:
+                h = p.grad.cpu()                            # gloo only ever sees host tensors
+                dist.all_reduce(h, op=dist.ReduceOp.SUM, group=group)
+                p.grad.copy_(h)
+            else:
+                pending.append(dist.all_reduce(p.grad, op=dist.ReduceOp.SUM, group=group, async_op=True))
+        for w in pending:
+            w.wait()
+    return 1.0 / world
+
+
+class GaussianAdam:
+    """torch.optim.Adam as the reference configures it (scene/gaussian_model.py:154-163), fused.
+
+    ``params``: name -> tensor, in the reference's group names (xyz, f_dc, f_rest, opacity, scaling,
+    rotation); ``lrs``: name -> learning rate.  State (exp_avg, exp_avg_sq, step) matches
+    torch.optim.Adam's, so a reference checkpoint's optimiser state maps one to one."""
+
+    def __init__(self, params: Dict[str, torch.Tensor], lrs: Dict[str, float], betas=(0.9, 0.999),
+                 eps: float = 1e-15):
+        if len(params) > MAX_TENSORS:
+            raise ValueError(f"at most {MAX_TENSORS} tensors per fused step")
+        for name, p in params.items():
+            if not p.is_cuda or p.dtype != torch.float32 or not p.is_contiguous():
+                raise ValueError(f"{name}: parameters must be contiguous float32 tensors on the GPU")
+        self.params, self.lrs = dict(params), dict(lrs)
+        self.betas, self.eps = betas, eps
+        self.step_count = 0
+        self.exp_avg = {k: torch.zeros_like(p) for k, p in params.items()}
+        self.exp_avg_sq = {k: torch.zeros_like(p) for k, p in params.items()}
+
+    @classmethod
+    def for_model(cls, model, opt: Optional[OptimizationParams] = None, spatial_lr_scale: float = 1.0):
+        """The six groups of training_setup (scene/gaussian_model.py:154-161)."""
+        opt = opt or OptimizationParams()
+        params = {"xyz": model._xyz, "f_dc": model._features_dc, "f_rest": model._features_rest,
+                  "opacity": model._opacity, "scaling": model._scaling, "rotation": model._rotation}
+        lrs = {"xyz": opt.position_lr_init * spatial_lr_scale, "f_dc": opt.feature_lr, "f_rest": opt.feature_lr / 20.0,
+               "opacity": opt.opacity_lr, "scaling": opt.scaling_lr, "rotation": opt.rotation_lr}
+        o = cls(params, lrs)
+        o.schedule = (opt.position_lr_init * spatial_lr_scale, opt.position_lr_final * spatial_lr_scale,
+                      opt.position_lr_delay_mult, opt.position_lr_max_steps)
+        return o
+
+    def update_learning_rate(self, iteration: int) -> float:
+        """scene/gaussian_model.py:169-175: only the position group is scheduled."""
+        lr_init, lr_final, mult, max_steps = self.schedule
+        lr = expon_lr(iteration, lr_init, lr_final, lr_delay_mult=mult, max_steps=max_steps)
+        self.lrs["xyz"] = lr
+        return lr
+
+    @torch.no_grad()
+    def step(self, grads: Optional[Dict[str, torch.Tensor]] = None, grad_scale: float = 1.0) -> None:
+        """One Adam update of every tensor that has a gradient (``grads[name]`` or ``param.grad``)."""
+        self.step_count += 1
+        arr = (_AdamTensor * MAX_TENSORS)()
+        n = 0
+        keep: List[torch.Tensor] = []
+        for name, p in self.params.items():
+            g = grads[name] if grads is not None else p.grad
+            if g is None:
+                continue
+            g = _dgr._f32(g, f"grad of {name}")
+            if g.numel() != p.numel():
+                raise ValueError(f"{name}: gradient has {g.numel()} elements, parameter {p.numel()}")
+            keep.append(g)
+            arr[n] = _AdamTensor(p.data_ptr(), g.data_ptr(), self.exp_avg[name].data_ptr(),
+                                 self.exp_avg_sq[name].data_ptr(), p.numel(), float(self.lrs[name]), 0)
+            n += 1
+        _dgr._run("adam_step", _lib.gsr_adam_step, n, arr, float(self.betas[0]), float(self.betas[1]),
+                  float(self.eps), int(self.step_count), float(grad_scale), _dgr._stream())
+
+    def zero_grad(self, set_to_none: bool = True) -> None:
+        """train.py:128."""
+        for p in self.params.values():
+            if set_to_none:
+                p.grad = None
+            elif p.grad is not None:
+                p.grad.zero_()

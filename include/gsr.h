@@ -225,6 +225,28 @@ int gsr_loss_fwd(int C, int H, int W, const float* img, const float* gt, float l
 int gsr_loss_bwd(int C, int H, int W, const float* img, const float* gt, const float* dmaps,
                  const float* grad_out, float lambda_dssim, float* grad_img, void* stream);
 
+/* ---- Optimiser step ----------------------------------------------------------
+ * The update that follows every backward in the reference's loop
+ * (train.py:126-128): torch.optim.Adam over the model's six parameter tensors,
+ * one learning rate per tensor, eps = 1e-15, betas (0.9, 0.999), no weight decay
+ * (scene/gaussian_model.py:154-163).  One launch updates all tensors in place:
+ * param, exp_avg, exp_avg_sq (n floats each) from grad * grad_scale.  `step`
+ * is the 1-based count of updates including this one (bias correction).
+ * h_tensors is a HOST array of `count` <= GSR_ADAM_MAX_TENSORS descriptors whose
+ * pointers are device pointers; `vec4` is filled in by the library. */
+#define GSR_ADAM_MAX_TENSORS 8
+typedef struct GsrAdamTensor {
+  float* param;
+  const float* grad;
+  float* exp_avg;
+  float* exp_avg_sq;
+  size_t n;
+  float lr;
+  int vec4;
+} GsrAdamTensor;
+int gsr_adam_step(int count, const GsrAdamTensor* h_tensors, double beta1, double beta2, double eps,
+                  int step, float grad_scale, void* stream);
+
 #ifdef __cplusplus
 }
 #endif

@@ -91,3 +91,57 @@ def test_two_ranks_match_one(tmp_path):
     assert results[0][2] == [0, 2] and results[1][2] == [1, 3]
     assert abs(results[0][1] - results[1][1]) < 1e-7          # both ranks hold the same reduced loss
     assert abs(results[0][1] - float(want)) < 1e-6
+
+
+def _arena_worker(rank, world, port, q):
+    _setup_path()
+    from gsplat_host.optim import GradArena
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    params = {"xyz": torch.zeros(7, 3), "opacity": torch.zeros(7, 1), "rotation": torch.zeros(7, 4)}
+    arena = GradArena(params)
+    arena.attach(params)
+    g = torch.Generator().manual_seed(100 + rank)
+    for k, p in params.items():
+        p.grad.copy_(torch.randn(p.shape, generator=g))          # what this rank's backward left behind
+    separate = {k: torch.nn.Parameter(torch.zeros_like(p)) for k, p in params.items()}
+    for k, p in separate.items():
+        p.grad = params[k].grad.clone()                          # the same gradients as free-standing tensors
+    scale = arena.all_reduce()
+    from gsplat_host.optim import all_reduce_gradients
+    assert all_reduce_gradients(separate) == scale
+    for k in params:
+        assert torch.equal(separate[k].grad, params[k].grad)     # per-tensor collectives give the same sums
+    q.put((rank, scale, {k: (p.grad * scale).clone() for k, p in params.items()}))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_gradient_arena_all_reduce_gives_the_mean_gradient():
+    """Data-parallel training: every rank's gradients sit in one flat buffer, one all-reduce sums
+    them, and the factor handed to the optimiser step turns the sum into the mean."""
+    _setup_path()
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        port = s.getsockname()[1]
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    procs = [ctx.Process(target=_arena_worker, args=(r, 2, port, q)) for r in range(2)]
+    for p in procs:
+        p.start()
+    results = sorted((q.get(timeout=120) for _ in procs), key=lambda r: r[0])
+    for p in procs:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    want = {}
+    for k, shape in (("xyz", (7, 3)), ("opacity", (7, 1)), ("rotation", (7, 4))):
+        want[k] = 0
+    for rank in range(2):
+        g = torch.Generator().manual_seed(100 + rank)
+        for k, shape in (("xyz", (7, 3)), ("opacity", (7, 1)), ("rotation", (7, 4))):
+            want[k] = want[k] + torch.randn(shape, generator=g) / 2
+    for rank, scale, grads in results:
+        assert scale == 0.5
+        for k in want:
+            assert torch.allclose(grads[k], want[k], atol=1e-6), (rank, k)
