@@ -247,6 +247,18 @@ typedef struct GsrAdamTensor {
 int gsr_adam_step(int count, const GsrAdamTensor* h_tensors, double beta1, double beta2, double eps,
                   int step, float grad_scale, void* stream);
 
+/* ---- Initial scales: mean squared distance to the three nearest neighbours ----
+ * distCUDA2 of the reference's second native submodule, simple_knn (call site
+ * scene/gaussian_model.py:134, used once, to initialise the scales; the
+ * submodule directory is empty in the reference tree).  points (P,3) ->
+ * mean_dist2 (P): mean of the three smallest squared distances to the other
+ * points (of fewer when P < 4; 0 when P = 1), exact, each distance computed as
+ * ((dx*dx + dy*dy) + dz*dz) in fp32 and the mean as ((d0 + d1) + d2) / 3 with
+ * d0 <= d1 <= d2. */
+size_t gsr_knn3_bytes(int P);
+int gsr_knn3_mean_dist2(int P, const float* points, float* mean_dist2, void* scratch,
+                        size_t scratch_bytes, void* stream);
+
 #ifdef __cplusplus
 }
 #endif
