@@ -40,12 +40,11 @@
 namespace {
 
 constexpr int kBlock = 256;
-constexpr int kSuper = 16;                 // supercell side in tiles = tiles per cell
+constexpr int kSuper = GSR_SUPERCELL;      // supercell side in tiles = tiles per cell
 constexpr uint32_t kPiece1 = 2048;         // list entries per block, per level
 constexpr uint32_t kPiece2 = 2048;
 constexpr uint32_t kPiece3 = 4096;
 constexpr int kScanBlock = 1024;
-constexpr int kTotalsBlocks = 256;
 
 typedef unsigned long long u64;
 
@@ -67,38 +66,7 @@ inline Grid make_grid(int W, int H) {
 
 inline uint32_t div_up_u(uint32_t a, uint32_t b) { return (a + b - 1) / b; }
 
-inline unsigned bits_for(unsigned n) {  // smallest b with 2^b >= n, at least 1
-  unsigned b = 1;
-  while ((1ull << b) < n) b++;
-  return b;
-}
-
-// Layout of the 64-bit word that travels through the depth sort:
-// index | x0 << bi | (x1 - 1) << (bi + bx) | y0 << (bi + 2 bx) | (y1 - 1) << (bi + 2 bx + by).
-struct Pack {
-  uint32_t bi, bx, by;
-  __host__ __device__ uint32_t bits() const { return bi + 2 * bx + 2 * by; }
-  __device__ __forceinline__ u64 pack(uint32_t i, uint32_t x0, uint32_t x1m, uint32_t y0, uint32_t y1m) const {
-    return (u64)i | ((u64)x0 << bi) | ((u64)x1m << (bi + bx)) | ((u64)y0 << (bi + 2 * bx)) |
-           ((u64)y1m << (bi + 2 * bx + by));
-  }
-  __device__ __forceinline__ uint32_t index(u64 v) const { return (uint32_t)(v & ((1ull << bi) - 1ull)); }
-  __device__ __forceinline__ void rect(u64 v, uint32_t& x0, uint32_t& x1m, uint32_t& y0, uint32_t& y1m) const {
-    const uint32_t mx = (1u << bx) - 1u, my = (1u << by) - 1u;
-    x0 = (uint32_t)(v >> bi) & mx;
-    x1m = (uint32_t)(v >> (bi + bx)) & mx;
-    y0 = (uint32_t)(v >> (bi + 2 * bx)) & my;
-    y1m = (uint32_t)(v >> (bi + 2 * bx + by)) & my;
-  }
-};
-
-inline Pack make_pack(int P, const Grid& g) {
-  Pack k;
-  k.bi = bits_for((unsigned)(P > 1 ? P : 2));
-  k.bx = bits_for((unsigned)g.gx);
-  k.by = bits_for((unsigned)g.gy);
-  return k;
-}
+using gsr::Pack;
 
 // ---------------------------------------------------------------------------
 // totals: N = tile instances, E1 = supercell entries, E2 = cell entries, V = visible Gaussians
@@ -109,35 +77,7 @@ __device__ __forceinline__ uint32_t wave_sum(uint32_t v) {
   return v;
 }
 
-// Every block leaves its four partial sums in partials[4 * block + k]; no atomics.
-// Also packs index and rectangle of every Gaussian into the word the depth sort carries.
-__global__ void __launch_bounds__(kBlock) totals_partial_kernel(int P, Pack pk, const uint2* __restrict__ rects,
-                                                                uint32_t* __restrict__ partials,
-                                                                u64* __restrict__ sort_vals) {
-  __shared__ uint32_t s_part[4][4];
-  uint32_t n = 0, e1 = 0, e2 = 0, v = 0;
-  for (int i = blockIdx.x * kBlock + threadIdx.x; i < P; i += gridDim.x * kBlock) {
-    const uint2 r = rects[i];
-    const uint32_t x0 = r.x & 0xffffu, y0 = r.x >> 16, x1 = r.y & 0xffffu, y1 = r.y >> 16;
-    sort_vals[i] = (x1 > x0 && y1 > y0) ? pk.pack((uint32_t)i, x0, x1 - 1, y0, y1 - 1) : (u64)(uint32_t)i;
-    if (x1 > x0 && y1 > y0) {
-      const uint32_t strips = ((x1 - 1) / kSuper) - (x0 / kSuper) + 1;
-      const uint32_t bands = ((y1 - 1) / kSuper) - (y0 / kSuper) + 1;
-      n += (x1 - x0) * (y1 - y0);
-      e1 += strips * bands;
-      e2 += strips * (y1 - y0);
-      v += 1;
-    }
-  }
-  n = wave_sum(n); e1 = wave_sum(e1); e2 = wave_sum(e2); v = wave_sum(v);
-  const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
-  if (lane == 0) { s_part[wave][0] = n; s_part[wave][1] = e1; s_part[wave][2] = e2; s_part[wave][3] = v; }
-  __syncthreads();
-  if (threadIdx.x < 4)
-    partials[4 * blockIdx.x + threadIdx.x] =
-        s_part[0][threadIdx.x] + s_part[1][threadIdx.x] + s_part[2][threadIdx.x] + s_part[3][threadIdx.x];
-}
-
+// Sums the per-block partial records the preprocess geometry kernel leaves behind.
 __global__ void __launch_bounds__(kBlock) totals_final_kernel(int blocks, const uint32_t* __restrict__ partials,
                                                               uint32_t* __restrict__ totals) {
   __shared__ uint32_t s_part[4][4];
@@ -550,22 +490,9 @@ ListsLayout lists_layout(uint32_t V, uint32_t E1, uint32_t E2, const Grid& g) {
 
 }  // namespace
 
-extern "C" int gsr_bin_totals(int P, int W, int H, const uint32_t* rects, uint32_t* totals, uint64_t* sort_vals,
-                              void* stream) {
-  GSR_REQUIRE(P >= 0 && W > 0 && H > 0, "bin_totals: bad sizes");
-  GSR_REQUIRE(totals && (P == 0 || (rects && sort_vals)), "bin_totals: null pointer");
-  GSR_REQUIRE(((uintptr_t)totals & 15) == 0, "bin_totals: totals must be 16-byte aligned");
-  const Grid g = make_grid(W, H);
-  const Pack pk = make_pack(P, g);
-  GSR_REQUIRE(pk.bits() <= 64, "bin_totals: %d Gaussians on a %dx%d tile grid do not fit the 64-bit sort value", P,
-              g.gx, g.gy);
-  hipStream_t st = (hipStream_t)stream;
-  const int blocks = P == 0 ? 0 : (gsr::div_up(P, kBlock) < kTotalsBlocks ? gsr::div_up(P, kBlock) : kTotalsBlocks);
-  if (blocks)
-    hipLaunchKernelGGL(totals_partial_kernel, dim3(blocks), dim3(kBlock), 0, st, P, pk, (const uint2*)rects,
-                       totals + 4, (u64*)sort_vals);
-  hipLaunchKernelGGL(totals_final_kernel, dim3(1), dim3(kBlock), 0, st, blocks, totals + 4, totals);
-  return gsr::check_launch("bin_totals");
+int gsr::launch_totals_final(int blocks, const uint32_t* partials, uint32_t* totals, hipStream_t stream) {
+  hipLaunchKernelGGL(totals_final_kernel, dim3(1), dim3(kBlock), 0, stream, blocks, partials, totals);
+  return gsr::check_launch("totals");
 }
 
 extern "C" size_t gsr_bin_sort_bytes(int P) {
@@ -621,7 +548,7 @@ extern "C" int gsr_bin_lists(int P, uint32_t V, uint32_t N, uint32_t E1, uint32_
   char* base = (char*)scratch;
   LevelArgs a{};
   a.g = g;
-  a.pk = make_pack(P, g);
+  a.pk = gsr::make_pack(P, g.gx, g.gy);
   GSR_REQUIRE(a.pk.bits() <= 64, "bin_lists: sizes do not fit the 64-bit sort value");
   a.V = V;
 

@@ -23,6 +23,49 @@ inline int check_launch(const char* what) {
 inline int div_up(int a, int b) { return (a + b - 1) / b; }
 inline size_t align_up(size_t v, size_t a) { return (v + a - 1) / a * a; }
 
+inline unsigned bits_for(unsigned n) {  // smallest b with 2^b >= n, at least 1
+  unsigned b = 1;
+  while ((1ull << b) < n) b++;
+  return b;
+}
+
+// Layout of the 64-bit word that travels through the depth sort of the binning:
+// index | x0 << bi | (x1 - 1) << (bi + bx) | y0 << (bi + 2 bx) | (y1 - 1) << (bi + 2 bx + by),
+// (x0, y0, x1, y1) the Gaussian's tile rectangle.  The preprocess writes it, the binning reads it.
+struct Pack {
+  uint32_t bi, bx, by;
+  __host__ __device__ uint32_t bits() const { return bi + 2 * bx + 2 * by; }
+  __device__ __forceinline__ unsigned long long pack(uint32_t i, uint32_t x0, uint32_t x1m, uint32_t y0,
+                                                     uint32_t y1m) const {
+    typedef unsigned long long u64;
+    return (u64)i | ((u64)x0 << bi) | ((u64)x1m << (bi + bx)) | ((u64)y0 << (bi + 2 * bx)) |
+           ((u64)y1m << (bi + 2 * bx + by));
+  }
+  __device__ __forceinline__ uint32_t index(unsigned long long v) const {
+    return (uint32_t)(v & ((1ull << bi) - 1ull));
+  }
+  __device__ __forceinline__ void rect(unsigned long long v, uint32_t& x0, uint32_t& x1m, uint32_t& y0,
+                                       uint32_t& y1m) const {
+    const uint32_t mx = (1u << bx) - 1u, my = (1u << by) - 1u;
+    x0 = (uint32_t)(v >> bi) & mx;
+    x1m = (uint32_t)(v >> (bi + bx)) & mx;
+    y0 = (uint32_t)(v >> (bi + 2 * bx)) & my;
+    y1m = (uint32_t)(v >> (bi + 2 * bx + by)) & my;
+  }
+};
+
+inline Pack make_pack(int P, int tiles_x, int tiles_y) {
+  Pack k;
+  k.bi = bits_for((unsigned)(P > 1 ? P : 2));
+  k.bx = bits_for((unsigned)tiles_x);
+  k.by = bits_for((unsigned)tiles_y);
+  return k;
+}
+
+// Sums `blocks` partial records of four counters (partials[4 * b + k]) into totals[0..3];
+// defined with the binning kernels.
+int launch_totals_final(int blocks, const uint32_t* partials, uint32_t* totals, hipStream_t stream);
+
 }  // namespace gsr
 
 #define GSR_REQUIRE(cond, ...)                                   \

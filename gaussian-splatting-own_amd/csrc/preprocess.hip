@@ -195,93 +195,148 @@ __device__ __forceinline__ float quat_norm(const float* q) {
   return fmaxf(sqrtf(q[0] * q[0] + q[1] * q[1] + q[2] * q[2] + q[3] * q[3]), 1e-12f);
 }
 
-struct FwdArgs {
-  int raw, n_rest; const float* shs_rest;
-  int P, M, W, H;
+// The forward runs as two kernels so that a host can overlap them: the geometry kernel produces
+// everything the binning needs (and is all the depth sort waits for), the colour kernel streams
+// the SH coefficients (4/5 of the input bytes) and is only needed by the blend.
+struct GeoArgs {
+  int raw, P, W, H;
   const float* means3D; const float* scales; const float* rotations; const float* opacities;
-  const float* shs; const float* colors_precomp; const float* cov3D_precomp;
-  const float* view; const float* proj; const float* campos;
+  const float* cov3D_precomp; const float* view; const float* proj;
   float scale_modifier, tanfovx, tanfovy;
+  gsr::Pack pack;
   uint32_t* records; int32_t* radii; uint32_t* tiles_touched; uint32_t* depth_keys; uint32_t* rects;
+  unsigned long long* sort_vals; uint32_t* partials;
+};
+
+__device__ __forceinline__ uint32_t wave_sum_u32(uint32_t v) {
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o);
+  return v;
+}
+
+__global__ void __launch_bounds__(kBlock) preprocess_geometry_kernel(GeoArgs a) {
+  __shared__ uint32_t s_part[kBlock / 64][4];
+  const int i = blockIdx.x * kBlock + threadIdx.x;
+  bool vis = false;
+  int radius = 0, x0 = 0, y0 = 0, x1 = 0, y1 = 0;
+  float pxs = 0.f, pys = 0.f, conA = 0.f, conB = 0.f, conC = 0.f, hx = -1.f, hy = -1.f;
+  float opacity = 0.f, depth = 0.f;
+  if (i < a.P) {
+    const float px3 = a.means3D[3 * i], py3 = a.means3D[3 * i + 1], pz3 = a.means3D[3 * i + 2];
+    const Vec3 pv = xform43(a.view, px3, py3, pz3);
+    depth = pv.z;
+    vis = pv.z > GSR_NEAR_CULL;
+    if (vis) {
+      const float* PV = a.proj;
+      const float hxh = PV[0] * px3 + PV[4] * py3 + PV[8] * pz3 + PV[12];
+      const float hyh = PV[1] * px3 + PV[5] * py3 + PV[9] * pz3 + PV[13];
+      const float hwh = PV[3] * px3 + PV[7] * py3 + PV[11] * pz3 + PV[15];
+      const float pw = 1.0f / (hwh + GSR_W_EPS);
+      const float ndcx = hxh * pw, ndcy = hyh * pw;
+
+      float c6[6];
+      if (a.cov3D_precomp) {
+#pragma unroll
+        for (int k = 0; k < 6; k++) c6[k] = a.cov3D_precomp[6 * (size_t)i + k];
+      } else {
+        float s[3] = {a.scales[3 * i], a.scales[3 * i + 1], a.scales[3 * i + 2]};
+        const float4 qv = reinterpret_cast<const float4*>(a.rotations)[i];
+        float q[4] = {qv.x, qv.y, qv.z, qv.w};
+        if (a.raw) {
+          s[0] = expf(s[0]); s[1] = expf(s[1]); s[2] = expf(s[2]);
+          const float n = quat_norm(q);
+          q[0] = q[0] / n; q[1] = q[1] / n; q[2] = q[2] / n; q[3] = q[3] / n;
+        }
+        cov3d_from_scale_rot(s, a.scale_modifier, q, c6);
+      }
+      Ewa e;
+      ewa_project(a.view, a.W, a.H, a.tanfovx, a.tanfovy, pv, c6, e);
+      const float det = e.a * e.c - e.b * e.b;
+      vis = det != 0.0f;
+      if (vis) {
+        const float det_inv = 1.0f / det;
+        conA = e.c * det_inv; conB = -e.b * det_inv; conC = e.a * det_inv;
+        const float mid = 0.5f * (e.a + e.c);
+        const float disc = sqrtf(fmaxf(GSR_LAMBDA_FLOOR, mid * mid - det));
+        const float lam1 = mid + disc, lam2 = mid - disc;
+        const float rf = ceilf(GSR_RADIUS_SIGMAS * sqrtf(fmaxf(lam1, lam2)));
+        radius = (rf < 2147483520.0f) ? (int)rf : 2147483647;
+        pxs = ((ndcx + 1.0f) * (float)a.W - 1.0f) * 0.5f;
+        pys = ((ndcy + 1.0f) * (float)a.H - 1.0f) * 0.5f;
+        const int gx = (a.W + GSR_TILE_X - 1) / GSR_TILE_X, gy = (a.H + GSR_TILE_Y - 1) / GSR_TILE_Y;
+        const float rr = (float)radius;
+        x0 = (int)fminf((float)gx, fmaxf(0.0f, (pxs - rr) / (float)GSR_TILE_X));
+        y0 = (int)fminf((float)gy, fmaxf(0.0f, (pys - rr) / (float)GSR_TILE_Y));
+        x1 = (int)fminf((float)gx, fmaxf(0.0f, (pxs + rr + (float)(GSR_TILE_X - 1)) / (float)GSR_TILE_X));
+        y1 = (int)fminf((float)gy, fmaxf(0.0f, (pys + rr + (float)(GSR_TILE_Y - 1)) / (float)GSR_TILE_Y));
+        vis = (x1 - x0) * (y1 - y0) > 0;
+        opacity = a.raw ? sigmoidf(a.opacities[i]) : a.opacities[i];
+        // Half extents of the region where alpha can reach 1/255: the ellipse
+        // d^T conic d <= 2 ln(255 o) spans sqrt(2 ln(255 o) * cov_xx) in x.
+        // Widened a little so that rounding can never make it exclusive.
+        const float tau = 2.0f * __logf(255.0f * opacity);
+        if (tau > 0.0f) {
+          hx = sqrtf(tau * e.a) * 1.0005f + 0.01f;
+          hy = sqrtf(tau * e.c) * 1.0005f + 0.01f;
+        }
+      }
+    }
+    uint4* rec = reinterpret_cast<uint4*>(a.records) + (size_t)i * 4;
+    if (!vis) {
+      a.radii[i] = 0;
+      a.tiles_touched[i] = 0;
+      a.depth_keys[i] = 0xFFFFFFFFu;
+      reinterpret_cast<uint2*>(a.rects)[i] = make_uint2(0u, 0u);
+      a.sort_vals[i] = (unsigned long long)(uint32_t)i;
+      rec[3] = make_uint4(0u, 0u, 0u, 0u);
+    } else {
+      const uint32_t rmin = (uint32_t)x0 | ((uint32_t)y0 << 16), rmax = (uint32_t)x1 | ((uint32_t)y1 << 16);
+      a.radii[i] = radius;
+      a.tiles_touched[i] = (uint32_t)((x1 - x0) * (y1 - y0));
+      a.depth_keys[i] = __float_as_uint(depth);
+      reinterpret_cast<uint2*>(a.rects)[i] = make_uint2(rmin, rmax);
+      a.sort_vals[i] = a.pack.pack((uint32_t)i, (uint32_t)x0, (uint32_t)x1 - 1u, (uint32_t)y0, (uint32_t)y1 - 1u);
+      rec[0] = make_uint4(__float_as_uint(pxs), __float_as_uint(pys), __float_as_uint(hx), __float_as_uint(hy));
+      rec[1] = make_uint4(__float_as_uint(conA), __float_as_uint(conB), __float_as_uint(conC),
+                          __float_as_uint(opacity));
+      rec[3] = make_uint4(__float_as_uint(depth), rmin, rmax, (uint32_t)radius);
+    }
+  }
+  // list sizes of the binning (tile instances, supercell entries, cell entries, visible Gaussians):
+  // one partial record per block, summed by a second small kernel; no atomics
+  uint32_t n = 0, e1 = 0, e2 = 0, v = 0;
+  if (vis) {
+    const uint32_t strips = (uint32_t)((x1 - 1) / GSR_SUPERCELL - x0 / GSR_SUPERCELL + 1);
+    const uint32_t bands = (uint32_t)((y1 - 1) / GSR_SUPERCELL - y0 / GSR_SUPERCELL + 1);
+    n = (uint32_t)((x1 - x0) * (y1 - y0));
+    e1 = strips * bands;
+    e2 = strips * (uint32_t)(y1 - y0);
+    v = 1u;
+  }
+  n = wave_sum_u32(n); e1 = wave_sum_u32(e1); e2 = wave_sum_u32(e2); v = wave_sum_u32(v);
+  const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+  if (lane == 0) { s_part[wave][0] = n; s_part[wave][1] = e1; s_part[wave][2] = e2; s_part[wave][3] = v; }
+  __syncthreads();
+  if (threadIdx.x < 4) {
+    uint32_t t = 0;
+#pragma unroll
+    for (int w = 0; w < kBlock / 64; w++) t += s_part[w][threadIdx.x];
+    a.partials[4 * blockIdx.x + threadIdx.x] = t;
+  }
+}
+
+struct ColorArgs {
+  int P, M, n_rest;
+  const float* means3D; const float* shs; const float* shs_rest; const float* colors_precomp; const float* campos;
+  const int32_t* radii; uint32_t* records;
 };
 
 template <int D>
-__global__ void __launch_bounds__(kBlock) preprocess_fwd_kernel(FwdArgs a) {
-  const int i = blockIdx.x * kBlock + threadIdx.x;
-  if (i >= a.P) return;
-  uint4* rec = reinterpret_cast<uint4*>(a.records) + (size_t)i * 4;
-
-  const float px3 = a.means3D[3 * i], py3 = a.means3D[3 * i + 1], pz3 = a.means3D[3 * i + 2];
-  const Vec3 pv = xform43(a.view, px3, py3, pz3);
-  bool vis = pv.z > GSR_NEAR_CULL;
-
-  int radius = 0, x0 = 0, y0 = 0, x1 = 0, y1 = 0;
-  float pxs = 0.f, pys = 0.f, conA = 0.f, conB = 0.f, conC = 0.f, hx = -1.f, hy = -1.f;
-  float opacity = 0.f;
-  if (vis) {
-    const float* PV = a.proj;
-    const float hxh = PV[0] * px3 + PV[4] * py3 + PV[8] * pz3 + PV[12];
-    const float hyh = PV[1] * px3 + PV[5] * py3 + PV[9] * pz3 + PV[13];
-    const float hwh = PV[3] * px3 + PV[7] * py3 + PV[11] * pz3 + PV[15];
-    const float pw = 1.0f / (hwh + GSR_W_EPS);
-    const float ndcx = hxh * pw, ndcy = hyh * pw;
-
-    float c6[6];
-    if (a.cov3D_precomp) {
-#pragma unroll
-      for (int k = 0; k < 6; k++) c6[k] = a.cov3D_precomp[6 * (size_t)i + k];
-    } else {
-      float s[3] = {a.scales[3 * i], a.scales[3 * i + 1], a.scales[3 * i + 2]};
-      const float4 qv = reinterpret_cast<const float4*>(a.rotations)[i];
-      float q[4] = {qv.x, qv.y, qv.z, qv.w};
-      if (a.raw) {
-        s[0] = expf(s[0]); s[1] = expf(s[1]); s[2] = expf(s[2]);
-        const float n = quat_norm(q);
-        q[0] = q[0] / n; q[1] = q[1] / n; q[2] = q[2] / n; q[3] = q[3] / n;
-      }
-      cov3d_from_scale_rot(s, a.scale_modifier, q, c6);
-    }
-    Ewa e;
-    ewa_project(a.view, a.W, a.H, a.tanfovx, a.tanfovy, pv, c6, e);
-    const float det = e.a * e.c - e.b * e.b;
-    vis = det != 0.0f;
-    if (vis) {
-      const float det_inv = 1.0f / det;
-      conA = e.c * det_inv; conB = -e.b * det_inv; conC = e.a * det_inv;
-      const float mid = 0.5f * (e.a + e.c);
-      const float disc = sqrtf(fmaxf(GSR_LAMBDA_FLOOR, mid * mid - det));
-      const float lam1 = mid + disc, lam2 = mid - disc;
-      const float rf = ceilf(GSR_RADIUS_SIGMAS * sqrtf(fmaxf(lam1, lam2)));
-      radius = (rf < 2147483520.0f) ? (int)rf : 2147483647;
-      pxs = ((ndcx + 1.0f) * (float)a.W - 1.0f) * 0.5f;
-      pys = ((ndcy + 1.0f) * (float)a.H - 1.0f) * 0.5f;
-      const int gx = (a.W + GSR_TILE_X - 1) / GSR_TILE_X, gy = (a.H + GSR_TILE_Y - 1) / GSR_TILE_Y;
-      const float rr = (float)radius;
-      x0 = (int)fminf((float)gx, fmaxf(0.0f, (pxs - rr) / (float)GSR_TILE_X));
-      y0 = (int)fminf((float)gy, fmaxf(0.0f, (pys - rr) / (float)GSR_TILE_Y));
-      x1 = (int)fminf((float)gx, fmaxf(0.0f, (pxs + rr + (float)(GSR_TILE_X - 1)) / (float)GSR_TILE_X));
-      y1 = (int)fminf((float)gy, fmaxf(0.0f, (pys + rr + (float)(GSR_TILE_Y - 1)) / (float)GSR_TILE_Y));
-      vis = (x1 - x0) * (y1 - y0) > 0;
-      opacity = a.raw ? sigmoidf(a.opacities[i]) : a.opacities[i];
-      // Half extents of the region where alpha can reach 1/255: the ellipse
-      // d^T conic d <= 2 ln(255 o) spans sqrt(2 ln(255 o) * cov_xx) in x.
-      // Widened a little so that rounding can never make it exclusive.
-      const float tau = 2.0f * __logf(255.0f * opacity);
-      if (tau > 0.0f) {
-        hx = sqrtf(tau * e.a) * 1.0005f + 0.01f;
-        hy = sqrtf(tau * e.c) * 1.0005f + 0.01f;
-      }
-    }
-  }
-  if (!vis) {
-    a.radii[i] = 0;
-    a.tiles_touched[i] = 0;
-    a.depth_keys[i] = 0xFFFFFFFFu;
-    reinterpret_cast<uint2*>(a.rects)[i] = make_uint2(0u, 0u);
-    rec[3] = make_uint4(0u, 0u, 0u, 0u);
-    return;
-  }
-
+__global__ void __launch_bounds__(kBlock) preprocess_color_kernel(ColorArgs a) {
+  // grid-stride: a host that runs this kernel beside others launches few blocks, so that it
+  // never occupies every wave slot of the chip
+  for (int i = blockIdx.x * kBlock + threadIdx.x; i < a.P; i += gridDim.x * kBlock) {
+  if (a.radii[i] <= 0) continue;
   float r = 0.f, g = 0.f, b = 0.f;
   unsigned clamped = 0;
   if (a.colors_precomp) {
@@ -290,6 +345,7 @@ __global__ void __launch_bounds__(kBlock) preprocess_fwd_kernel(FwdArgs a) {
     b = a.colors_precomp[3 * (size_t)i + 2];
   } else {
     // gaussian_renderer/__init__.py:75-78
+    const float px3 = a.means3D[3 * i], py3 = a.means3D[3 * i + 1], pz3 = a.means3D[3 * i + 2];
     float dx = px3 - a.campos[0], dy = py3 - a.campos[1], dz = pz3 - a.campos[2];
     const float len = sqrtf(dx * dx + dy * dy + dz * dz);
     dx = dx / len; dy = dy / len; dz = dz / len;
@@ -308,17 +364,9 @@ __global__ void __launch_bounds__(kBlock) preprocess_fwd_kernel(FwdArgs a) {
     }
     r = col[0]; g = col[1]; b = col[2];
   }
-
-  a.radii[i] = radius;
-  a.tiles_touched[i] = (uint32_t)((x1 - x0) * (y1 - y0));
-  a.depth_keys[i] = __float_as_uint(pv.z);
-  reinterpret_cast<uint2*>(a.rects)[i] = make_uint2((uint32_t)x0 | ((uint32_t)y0 << 16), (uint32_t)x1 | ((uint32_t)y1 << 16));
-  rec[0] = make_uint4(__float_as_uint(pxs), __float_as_uint(pys), __float_as_uint(hx), __float_as_uint(hy));
-  rec[1] = make_uint4(__float_as_uint(conA), __float_as_uint(conB), __float_as_uint(conC),
-                      __float_as_uint(opacity));
-  rec[2] = make_uint4(__float_as_uint(r), __float_as_uint(g), __float_as_uint(b), __float_as_uint(pv.z));
-  rec[3] = make_uint4((uint32_t)x0 | ((uint32_t)y0 << 16), (uint32_t)x1 | ((uint32_t)y1 << 16),
-                      (uint32_t)radius, clamped);
+  reinterpret_cast<uint4*>(a.records)[(size_t)i * 4 + 2] =
+      make_uint4(__float_as_uint(r), __float_as_uint(g), __float_as_uint(b), clamped);
+  }
 }
 
 __global__ void __launch_bounds__(kBlock) mark_visible_kernel(int P, const float* __restrict__ means3D,
@@ -356,7 +404,7 @@ __global__ void __launch_bounds__(kBlock, 4) preprocess_bwd_kernel(BwdArgs a) {
   const bool valid = i < a.P;
   uint4 r3 = make_uint4(0u, 0u, 0u, 0u);
   if (valid) r3 = reinterpret_cast<const uint4*>(a.records)[(size_t)i * 4 + 3];
-  const bool vis = valid && (int)r3.z > 0;
+  const bool vis = valid && (int)r3.w > 0;
   const float4* gsp = reinterpret_cast<const float4*>(a.dL_dsplat) + (size_t)i * (GSR_GRAD_WORDS / 4);
   float4 g0 = make_float4(0, 0, 0, 0), g1 = g0, g2 = g0;
   if (vis) {
@@ -476,7 +524,8 @@ __global__ void __launch_bounds__(kBlock, 4) preprocess_bwd_kernel(BwdArgs a) {
       float bas[N], sh[3 * N];
       sh_basis<D>(x, y, z, bas);
       load_sh<D>(a.shs, a.shs_rest ? a.shs_rest + (size_t)i * (a.n_rest * 3) : nullptr, a.M, i, sh);
-      const float dRGB[3] = {(r3.w & 1u) ? 0.f : g1.z, (r3.w & 2u) ? 0.f : g1.w, (r3.w & 4u) ? 0.f : g2.x};
+      const uint32_t clamped = a.records[(size_t)i * GSR_REC_WORDS + GSR_REC_CLAMPED];
+      const float dRGB[3] = {(clamped & 1u) ? 0.f : g1.z, (clamped & 2u) ? 0.f : g1.w, (clamped & 4u) ? 0.f : g2.x};
 #pragma unroll
       for (int k = 0; k < N; k++) {
         dsh[3 * k] = bas[k] * dRGB[0]; dsh[3 * k + 1] = bas[k] * dRGB[1]; dsh[3 * k + 2] = bas[k] * dRGB[2];
@@ -608,37 +657,78 @@ __global__ void __launch_bounds__(kBlock, 4) preprocess_bwd_kernel(BwdArgs a) {
 
 }  // namespace
 
+extern "C" size_t gsr_totals_words(int P) { return 4 + 4 * (size_t)(P > 0 ? gsr::div_up(P, kBlock) : 0); }
+
+extern "C" int gsr_preprocess_geometry(int P, int raw, const float* means3D, const float* scales, float scale_modifier,
+                                       const float* rotations, const float* opacities, const float* cov3D_precomp,
+                                       const float* viewmatrix, const float* projmatrix, int W, int H, float tanfovx,
+                                       float tanfovy, uint32_t* records, int32_t* radii, uint32_t* tiles_touched,
+                                       uint32_t* depth_keys, uint32_t* rects, uint64_t* sort_vals, uint32_t* totals,
+                                       void* stream) {
+  GSR_REQUIRE(P >= 0 && W > 0 && H > 0, "preprocess_geometry: bad sizes P=%d W=%d H=%d", P, W, H);
+  GSR_REQUIRE(totals && ((uintptr_t)totals & 15) == 0, "preprocess_geometry: totals must be non-null and 16-byte aligned");
+  hipStream_t st = (hipStream_t)stream;
+  if (P == 0) return gsr::launch_totals_final(0, totals + 4, totals, st);
+  GSR_REQUIRE(means3D && opacities && viewmatrix && projmatrix, "preprocess_geometry: null input");
+  GSR_REQUIRE(records && radii && tiles_touched && depth_keys && rects && sort_vals, "preprocess_geometry: null output");
+  GSR_REQUIRE(((scales != nullptr) && (rotations != nullptr)) != (cov3D_precomp != nullptr),
+              "preprocess_geometry: give exactly one of (scales, rotations) / cov3D_precomp");
+  GSR_REQUIRE(!(raw && cov3D_precomp), "preprocess_geometry: raw parameters and cov3D_precomp exclude each other");
+  GSR_REQUIRE(W <= 16 * 16 * 255 && H <= 16 * 16 * 255, "preprocess_geometry: image %dx%d too large", W, H);
+  const gsr::Pack pack = gsr::make_pack(P, gsr::div_up(W, GSR_TILE_X), gsr::div_up(H, GSR_TILE_Y));
+  GSR_REQUIRE(pack.bits() <= 64, "preprocess_geometry: %d Gaussians on a %dx%d image do not fit the 64-bit sort value",
+              P, W, H);
+  GeoArgs a{raw, P, W, H, means3D, scales, rotations, opacities, cov3D_precomp, viewmatrix, projmatrix,
+            scale_modifier, tanfovx, tanfovy, pack, records, radii, tiles_touched, depth_keys, rects,
+            (unsigned long long*)sort_vals, totals + 4};
+  const int blocks = gsr::div_up(P, kBlock);
+  hipLaunchKernelGGL(preprocess_geometry_kernel, dim3(blocks), dim3(kBlock), 0, st, a);
+  int rc = gsr::check_launch("preprocess_geometry");
+  if (rc) return rc;
+  return gsr::launch_totals_final(blocks, totals + 4, totals, st);
+}
+
+extern "C" int gsr_preprocess_color(int P, int D, int M, const float* means3D, const float* shs, const float* shs_rest,
+                                    int n_rest, const float* colors_precomp, const float* campos, const int32_t* radii,
+                                    uint32_t* records, int max_blocks, void* stream) {
+  GSR_REQUIRE(P >= 0, "preprocess_color: bad P");
+  if (P == 0) return GSR_OK;
+  GSR_REQUIRE(radii && records, "preprocess_color: null pointer");
+  GSR_REQUIRE((shs != nullptr) != (colors_precomp != nullptr), "preprocess_color: give exactly one of shs / colors_precomp");
+  GSR_REQUIRE(colors_precomp || (means3D && campos), "preprocess_color: null input");
+  GSR_REQUIRE(D >= 0 && D <= GSR_MAX_SH_DEGREE, "preprocess_color: SH degree %d unsupported (0..3)", D);
+  GSR_REQUIRE(!shs || M >= (D + 1) * (D + 1), "preprocess_color: M=%d too small for degree %d", M, D);
+  GSR_REQUIRE(!shs_rest || (shs && n_rest >= (D + 1) * (D + 1) - 1 && n_rest <= 15 && M == 1 + n_rest),
+              "preprocess_color: n_rest=%d does not hold degree %d", n_rest, D);
+  ColorArgs a{P, M, n_rest, means3D, shs, shs_rest, colors_precomp, campos, radii, records};
+  hipStream_t st = (hipStream_t)stream;
+  int blocks = gsr::div_up(P, kBlock);
+  if (max_blocks > 0 && blocks > max_blocks) blocks = max_blocks;
+  dim3 grid(blocks), block(kBlock);
+  const int d = shs ? D : 0;
+  switch (d) {
+    case 0: hipLaunchKernelGGL(preprocess_color_kernel<0>, grid, block, 0, st, a); break;
+    case 1: hipLaunchKernelGGL(preprocess_color_kernel<1>, grid, block, 0, st, a); break;
+    case 2: hipLaunchKernelGGL(preprocess_color_kernel<2>, grid, block, 0, st, a); break;
+    default: hipLaunchKernelGGL(preprocess_color_kernel<3>, grid, block, 0, st, a); break;
+  }
+  return gsr::check_launch("preprocess_color");
+}
+
 extern "C" int gsr_preprocess_fwd(int P, int D, int M, const float* means3D, const float* scales,
                                   float scale_modifier, const float* rotations, const float* opacities,
                                   const float* shs, const float* colors_precomp, const float* cov3D_precomp,
                                   const float* viewmatrix, const float* projmatrix, const float* campos,
                                   int W, int H, float tanfovx, float tanfovy, int prefiltered,
                                   uint32_t* records, int32_t* radii, uint32_t* tiles_touched,
-                                  uint32_t* depth_keys, uint32_t* rects, void* stream) {
+                                  uint32_t* depth_keys, uint32_t* rects, uint64_t* sort_vals, uint32_t* totals,
+                                  void* stream) {
   (void)prefiltered;
-  GSR_REQUIRE(P >= 0 && W > 0 && H > 0, "preprocess_fwd: bad sizes P=%d W=%d H=%d", P, W, H);
-  if (P == 0) return GSR_OK;
-  GSR_REQUIRE(means3D && opacities && viewmatrix && projmatrix && campos, "preprocess_fwd: null input");
-  GSR_REQUIRE(records && radii && tiles_touched && depth_keys && rects, "preprocess_fwd: null output");
-  GSR_REQUIRE((shs != nullptr) != (colors_precomp != nullptr), "preprocess_fwd: give exactly one of shs / colors_precomp");
-  GSR_REQUIRE(((scales != nullptr) && (rotations != nullptr)) != (cov3D_precomp != nullptr),
-              "preprocess_fwd: give exactly one of (scales, rotations) / cov3D_precomp");
-  GSR_REQUIRE(D >= 0 && D <= GSR_MAX_SH_DEGREE, "preprocess_fwd: SH degree %d unsupported (0..3)", D);
-  GSR_REQUIRE(!shs || M >= (D + 1) * (D + 1), "preprocess_fwd: M=%d too small for degree %d", M, D);
-  GSR_REQUIRE(W <= 16 * 65535 && H <= 16 * 65535, "preprocess_fwd: image too large");
-  FwdArgs a{0, 0, nullptr, P, M, W, H, means3D, scales, rotations, opacities, shs, colors_precomp, cov3D_precomp,
-            viewmatrix, projmatrix, campos, scale_modifier, tanfovx, tanfovy,
-            records, radii, tiles_touched, depth_keys, rects};
-  hipStream_t st = (hipStream_t)stream;
-  dim3 grid(gsr::div_up(P, kBlock)), block(kBlock);
-  const int d = shs ? D : 0;
-  switch (d) {
-    case 0: hipLaunchKernelGGL(preprocess_fwd_kernel<0>, grid, block, 0, st, a); break;
-    case 1: hipLaunchKernelGGL(preprocess_fwd_kernel<1>, grid, block, 0, st, a); break;
-    case 2: hipLaunchKernelGGL(preprocess_fwd_kernel<2>, grid, block, 0, st, a); break;
-    default: hipLaunchKernelGGL(preprocess_fwd_kernel<3>, grid, block, 0, st, a); break;
-  }
-  return gsr::check_launch("preprocess_fwd");
+  int rc = gsr_preprocess_geometry(P, 0, means3D, scales, scale_modifier, rotations, opacities, cov3D_precomp,
+                                   viewmatrix, projmatrix, W, H, tanfovx, tanfovy, records, radii, tiles_touched,
+                                   depth_keys, rects, sort_vals, totals, stream);
+  if (rc) return rc;
+  return gsr_preprocess_color(P, D, M, means3D, shs, nullptr, 0, colors_precomp, campos, radii, records, 0, stream);
 }
 
 extern "C" int gsr_mark_visible(int P, const float* means3D, const float* viewmatrix, uint8_t* present,
@@ -699,30 +789,15 @@ extern "C" int gsr_preprocess_fwd_raw(int P, int D, int n_rest, const float* xyz
                                       const float* viewmatrix, const float* projmatrix, const float* campos, int W,
                                       int H, float tanfovx, float tanfovy, uint32_t* records, int32_t* radii,
                                       uint32_t* tiles_touched, uint32_t* depth_keys, uint32_t* rects,
-                                      void* stream) {
-  GSR_REQUIRE(P >= 0 && W > 0 && H > 0, "preprocess_fwd_raw: bad sizes P=%d W=%d H=%d", P, W, H);
-  if (P == 0) return GSR_OK;
-  GSR_REQUIRE(xyz && scaling_raw && rotation_raw && opacity_raw && features_dc && viewmatrix && projmatrix && campos,
-              "preprocess_fwd_raw: null input");
-  GSR_REQUIRE(records && radii && tiles_touched && depth_keys && rects, "preprocess_fwd_raw: null output");
-  GSR_REQUIRE(D >= 0 && D <= GSR_MAX_SH_DEGREE, "preprocess_fwd_raw: SH degree %d unsupported (0..3)", D);
-  GSR_REQUIRE(n_rest >= (D + 1) * (D + 1) - 1 && n_rest <= 15 && (n_rest == 0 || features_rest),
-              "preprocess_fwd_raw: n_rest=%d does not hold degree %d", n_rest, D);
-  GSR_REQUIRE(W <= 16 * 65535 && H <= 16 * 65535, "preprocess_fwd_raw: image too large");
-  // with D == 0 and no rest tensor the dc tensor alone is a (P,1,3) shs tensor
-  const bool split = n_rest > 0;
-  FwdArgs a{1, n_rest, split ? features_rest : nullptr, P, 1 + n_rest, W, H, xyz, scaling_raw, rotation_raw,
-            opacity_raw, features_dc, nullptr, nullptr, viewmatrix, projmatrix, campos, scale_modifier, tanfovx,
-            tanfovy, records, radii, tiles_touched, depth_keys, rects};
-  hipStream_t st = (hipStream_t)stream;
-  dim3 grid(gsr::div_up(P, kBlock)), block(kBlock);
-  switch (D) {
-    case 0: hipLaunchKernelGGL(preprocess_fwd_kernel<0>, grid, block, 0, st, a); break;
-    case 1: hipLaunchKernelGGL(preprocess_fwd_kernel<1>, grid, block, 0, st, a); break;
-    case 2: hipLaunchKernelGGL(preprocess_fwd_kernel<2>, grid, block, 0, st, a); break;
-    default: hipLaunchKernelGGL(preprocess_fwd_kernel<3>, grid, block, 0, st, a); break;
-  }
-  return gsr::check_launch("preprocess_fwd_raw");
+                                      uint64_t* sort_vals, uint32_t* totals, void* stream) {
+  GSR_REQUIRE(P <= 0 || (scaling_raw && rotation_raw && features_dc), "preprocess_fwd_raw: null input");
+  int rc = gsr_preprocess_geometry(P, 1, xyz, scaling_raw, scale_modifier, rotation_raw, opacity_raw, nullptr,
+                                   viewmatrix, projmatrix, W, H, tanfovx, tanfovy, records, radii, tiles_touched,
+                                   depth_keys, rects, sort_vals, totals, stream);
+  if (rc) return rc;
+  // with no rest tensor the dc tensor alone is a (P,1,3) shs tensor
+  return gsr_preprocess_color(P, D, 1 + n_rest, xyz, features_dc, n_rest > 0 ? features_rest : nullptr, n_rest, nullptr,
+                              campos, radii, records, 0, stream);
 }
 
 extern "C" int gsr_preprocess_bwd_raw(int P, int D, int n_rest, const float* xyz, const float* scaling_raw,

@@ -33,7 +33,11 @@ _LIB_PATH = os.environ.get("GSR_HIP_LIB") or os.path.join(_HERE, "libgsr_hip.so"
 TILE = 16
 REC_WORDS = 16
 GRAD_WORDS = 16
-TOTALS_WORDS = 4 + 4 * 256
+# GSR_NO_OVERLAP=1 keeps the colour kernel on the caller's stream (A/B runs, debugging)
+_OVERLAP = os.environ.get("GSR_NO_OVERLAP", "0") in ("", "0")
+# workgroups of the overlapped colour kernel: one per CU leaves most wave slots to the binning
+_COLOR_BLOCKS = int(os.environ.get("GSR_COLOR_BLOCKS", "256"))
+_COLOR_AFTER_SORT = os.environ.get("GSR_COLOR_AFTER_SORT", "0") not in ("", "0")
 
 
 def _load():
@@ -48,11 +52,15 @@ def _load():
     lib.gsr_bin_lists_bytes.restype = C.c_size_t
     lib.gsr_bin_lists_bytes.argtypes = [C.c_uint32, C.c_uint32, C.c_uint32, C.c_int, C.c_int]
     vp, ci, cf = C.c_void_p, C.c_int, C.c_float
+    lib.gsr_totals_words.restype = C.c_size_t
+    lib.gsr_totals_words.argtypes = [ci]
+    lib.gsr_preprocess_geometry.argtypes = [ci, ci, vp, vp, cf, vp, vp, vp, vp, vp, ci, ci, cf, cf,
+                                            vp, vp, vp, vp, vp, vp, vp, vp]
+    lib.gsr_preprocess_color.argtypes = [ci, ci, ci, vp, vp, vp, ci, vp, vp, vp, vp, ci, vp]
     lib.gsr_preprocess_fwd.argtypes = [ci, ci, ci, vp, vp, cf, vp, vp, vp, vp, vp, vp, vp, vp, ci, ci, cf, cf, ci,
-                                       vp, vp, vp, vp, vp, vp]
+                                       vp, vp, vp, vp, vp, vp, vp, vp]
     lib.gsr_mark_visible.argtypes = [ci, vp, vp, vp, vp]
     u32 = C.c_uint32
-    lib.gsr_bin_totals.argtypes = [ci, ci, ci, vp, vp, vp, vp]
     lib.gsr_bin_sort.argtypes = [ci, vp, vp, vp, vp, C.c_size_t, vp]
     lib.gsr_bin_lists.argtypes = [ci, u32, u32, u32, u32, ci, ci, vp, vp, vp, vp, vp, C.c_size_t, vp]
     lib.gsr_blend_fwd.argtypes = [ci, ci, vp, vp, vp, vp, vp, vp, vp, vp]
@@ -60,7 +68,7 @@ def _load():
     lib.gsr_preprocess_bwd.argtypes = [ci, ci, ci, vp, vp, cf, vp, vp, vp, vp, vp, vp, ci, ci, cf, cf, vp, vp,
                                        vp, vp, vp, vp, vp, vp, vp, vp, vp]
     lib.gsr_preprocess_fwd_raw.argtypes = [ci, ci, ci, vp, vp, cf, vp, vp, vp, vp, vp, vp, vp, ci, ci, cf, cf,
-                                           vp, vp, vp, vp, vp, vp]
+                                           vp, vp, vp, vp, vp, vp, vp, vp]
     lib.gsr_preprocess_bwd_raw.argtypes = [ci, ci, ci, vp, vp, cf, vp, vp, vp, vp, vp, vp, vp, ci, ci, cf, cf,
                                            vp, vp, vp, vp, vp, vp, vp, vp, vp, vp]
     return lib
@@ -120,6 +128,17 @@ def _stream():
 
 
 _pinned = {}
+_side = {}
+
+
+def _side_stream(dev: torch.device) -> torch.cuda.Stream:
+    """The second stream (default priority) the colour kernel runs on, one per device."""
+    key = dev.index if dev.index is not None else torch.cuda.current_device()
+    st = _side.get(key)
+    if st is None:
+        st = _side[key] = torch.cuda.Stream(device=dev)
+    return st
+
 
 
 def _pinned_totals(dev: torch.device) -> torch.Tensor:
@@ -161,7 +180,7 @@ class ForwardState:
     """Everything the forward leaves behind: op outputs, what backward needs,
     and the intermediate buffers the parity tests inspect."""
     __slots__ = ("P", "M", "D", "W", "H", "records", "radii", "tiles_touched", "depth_keys", "sorted_vals", "rect_words",
-                 "num_rendered", "num_visible", "point_list", "ranges", "tile_ids_sorted", "color", "final_T", "n_contrib",
+                 "num_rendered", "num_visible", "dsplat", "point_list", "ranges", "tile_ids_sorted", "color", "final_T", "n_contrib",
                  "view", "proj", "campos", "bg")
 
     # views into the 64-byte records, named as the oracle names them
@@ -179,16 +198,16 @@ class ForwardState:
 
     @property
     def depths(self):
-        return self.records.view(torch.float32)[:, 11]
+        return self.records.view(torch.float32)[:, 12]
 
     @property
     def rects(self):
-        r = self.records[:, 12:14]
+        r = self.records[:, 13:15]
         return torch.stack([r[:, 0] & 0xFFFF, r[:, 0] >> 16, r[:, 1] & 0xFFFF, r[:, 1] >> 16], dim=1)
 
     @property
     def clamped(self):
-        c = self.records[:, 15]
+        c = self.records[:, 11]
         return torch.stack([c & 1, (c >> 1) & 1, (c >> 2) & 1], dim=1).to(torch.uint8)
 
     def sort_keys(self):
@@ -199,12 +218,13 @@ class ForwardState:
 
 def rasterize_forward(s: GaussianRasterizationSettings, means3D, opacities, shs=None, colors_precomp=None,
                       scales=None, rotations=None, cov3D_precomp=None, keep_tile_ids: bool = False,
-                      raw: Optional[dict] = None) -> ForwardState:
+                      raw: Optional[dict] = None, prepare_backward: bool = False) -> ForwardState:
     """preprocess -> bin -> blend on the current stream; one host read-back
     (the instance count) in the middle, as in the module it replaces.
     With ``raw`` (features_dc, features_rest, scaling, rotation, opacity: the model's raw
     parameters) the activations run inside the preprocess kernel and the activated
-    arguments are ignored."""
+    arguments are ignored.  ``prepare_backward`` also clears the accumulator of the blend backward
+    during the forward (off the critical path)."""
     means3D = _f32(means3D, "means3D")
     dev = means3D.device if means3D is not None else s.bg.device
     st = ForwardState()
@@ -231,28 +251,56 @@ def rasterize_forward(s: GaussianRasterizationSettings, means3D, opacities, shs=
     st.n_contrib = torch.empty((H, W), **u32)
     st.tile_ids_sorted = None
 
-    if P > 0 and raw is not None:
-        r = {k: _f32(v, k) for k, v in raw.items()}
-        n_rest = 0 if r["features_rest"] is None else r["features_rest"].shape[1]
-        st.M = 1 + n_rest
-        _run("preprocess_fwd", _lib.gsr_preprocess_fwd_raw, P, st.D, n_rest, _ptr(means3D), _ptr(r["scaling"]),
-             float(s.scale_modifier), _ptr(r["rotation"]), _ptr(r["opacity"]), _ptr(r["features_dc"]),
-             _ptr(r["features_rest"]), _ptr(st.view), _ptr(st.proj), _ptr(st.campos), W, H, float(s.tanfovx),
-             float(s.tanfovy), _ptr(st.records), _ptr(st.radii), _ptr(st.tiles_touched), _ptr(st.depth_keys),
-             _ptr(st.rect_words), stream)
-    elif P > 0:
-        _run("preprocess_fwd", _lib.gsr_preprocess_fwd, P, st.D, st.M, _ptr(means3D), _ptr(scales),
-             float(s.scale_modifier), _ptr(rotations), _ptr(opacities), _ptr(shs), _ptr(colors_precomp),
-             _ptr(cov3D_precomp), _ptr(st.view), _ptr(st.proj), _ptr(st.campos), W, H, float(s.tanfovx),
-             float(s.tanfovy), int(bool(s.prefiltered)), _ptr(st.records), _ptr(st.radii), _ptr(st.tiles_touched),
-             _ptr(st.depth_keys), _ptr(st.rect_words), stream)
+    st.dsplat = None
     N = E1 = E2 = V = 0
+    color_done = None
     if P > 0:
+        totals = torch.empty((_lib.gsr_totals_words(P),), **u32)
+        sort_vals = torch.empty((P,), dtype=torch.int64, device=dev)
+        if raw is not None:
+            r = {k: _f32(v, k) for k, v in raw.items()}
+            n_rest = 0 if r["features_rest"] is None else r["features_rest"].shape[1]
+            st.M = 1 + n_rest
+            geo = (1, _ptr(means3D), _ptr(r["scaling"]), float(s.scale_modifier), _ptr(r["rotation"]),
+                   _ptr(r["opacity"]), None)
+            col = (_ptr(r["features_dc"]), _ptr(r["features_rest"]), n_rest, None)
+        else:
+            geo = (0, _ptr(means3D), _ptr(scales), float(s.scale_modifier), _ptr(rotations), _ptr(opacities),
+                   _ptr(cov3D_precomp))
+            col = (_ptr(shs), None, 0, _ptr(colors_precomp))
+        _run("preprocess_geometry", _lib.gsr_preprocess_geometry, P, *geo, _ptr(st.view), _ptr(st.proj), W, H,
+             float(s.tanfovx), float(s.tanfovy), _ptr(st.records), _ptr(st.radii), _ptr(st.tiles_touched),
+             _ptr(st.depth_keys), _ptr(st.rect_words), _ptr(sort_vals), _ptr(totals), stream)
+
+        def color_pass():
+            _run("preprocess_color", _lib.gsr_preprocess_color, P, st.D, st.M, _ptr(means3D), col[0], col[1], col[2],
+                 col[3], _ptr(st.campos), _ptr(st.radii), _ptr(st.records), _COLOR_BLOCKS if _OVERLAP else 0, _stream())
+            if prepare_backward:
+                st.dsplat = torch.zeros((P, GRAD_WORDS), dtype=torch.float32, device=dev)
+
+        # SH -> RGB streams 4/5 of the stage's input bytes and only the blend needs it: it runs on a
+        # second stream beside the depth sort and the partitions, which are short dependent launches
+        # that leave HBM idle.  The backward's accumulator is cleared there too.
+        def overlapped_color_pass():
+            main, side = torch.cuda.current_stream(dev), _side_stream(dev)
+            ready = torch.cuda.Event()
+            ready.record(main)
+            side.wait_event(ready)
+            with torch.cuda.stream(side):
+                color_pass()
+                done = torch.cuda.Event()
+                done.record(side)
+            if st.dsplat is not None:
+                st.dsplat.record_stream(main)
+            return done
+
+        if not _OVERLAP:
+            color_pass()
+        elif not _COLOR_AFTER_SORT:
+            color_done = overlapped_color_pass()
+
         # The list sizes go to the host (the pipeline's one read-back) while the GPU sorts by depth:
         # the copy is queued before the sort and the host waits for the copy alone.
-        totals = torch.empty((TOTALS_WORDS,), **u32)
-        sort_vals = torch.empty((P,), dtype=torch.int64, device=dev)
-        _run("bin_totals", _lib.gsr_bin_totals, P, W, H, _ptr(st.rect_words), _ptr(totals), _ptr(sort_vals), stream)
         host = _pinned_totals(dev)
         host.copy_(totals[:4], non_blocking=True)
         copied = torch.cuda.Event()
@@ -261,6 +309,8 @@ def rasterize_forward(s: GaussianRasterizationSettings, means3D, opacities, shs=
         scratch = torch.empty((nb,), dtype=torch.uint8, device=dev)
         _run("bin_sort", _lib.gsr_bin_sort, P, _ptr(st.depth_keys), _ptr(sort_vals), _ptr(st.sorted_vals),
              _ptr(scratch), nb, stream)
+        if _OVERLAP and _COLOR_AFTER_SORT:
+            color_done = overlapped_color_pass()
         copied.synchronize()
         N, E1, E2, V = (int(v) & 0xFFFFFFFF for v in host.tolist())
     st.num_rendered, st.num_visible = N, V
@@ -271,6 +321,8 @@ def rasterize_forward(s: GaussianRasterizationSettings, means3D, opacities, shs=
     scratch = torch.empty((nb,), dtype=torch.uint8, device=dev)
     _run("bin_lists", _lib.gsr_bin_lists, P, V, N, E1, E2, W, H, _ptr(st.sorted_vals), _ptr(st.point_list),
          _ptr(st.ranges), _ptr(st.tile_ids_sorted), _ptr(scratch), nb, stream)
+    if color_done is not None:
+        torch.cuda.current_stream(dev).wait_event(color_done)
     _run("blend_fwd", _lib.gsr_blend_fwd, W, H, _ptr(st.ranges), _ptr(st.point_list), _ptr(st.records), _ptr(st.bg),
                               _ptr(st.color), _ptr(st.final_T), _ptr(st.n_contrib), stream)
     st.point_list = st.point_list[:N]
@@ -282,7 +334,9 @@ def rasterize_forward(s: GaussianRasterizationSettings, means3D, opacities, shs=
 def blend_backward(st: ForwardState, grad_color: torch.Tensor) -> torch.Tensor:
     """dL/dpixels (3,H,W) -> per-Gaussian sums (P,16); see GSR_GRAD_WORDS in gsr.h."""
     grad_color = _f32(grad_color, "grad_color")
-    dsplat = torch.zeros((st.P, GRAD_WORDS), dtype=torch.float32, device=grad_color.device)
+    dsplat, st.dsplat = st.dsplat, None                     # cleared during the forward, good for one backward
+    if dsplat is None:
+        dsplat = torch.zeros((st.P, GRAD_WORDS), dtype=torch.float32, device=grad_color.device)
     if st.P > 0 and st.num_rendered > 0:
         _run("blend_bwd", _lib.gsr_blend_bwd, st.W, st.H, _ptr(st.ranges), _ptr(st.point_list), _ptr(st.records), _ptr(st.bg),
                                   _ptr(st.final_T), _ptr(st.n_contrib), _ptr(grad_color), _ptr(dsplat), _stream())
@@ -366,7 +420,7 @@ class _RasterizeGaussiansRaw(torch.autograd.Function):
                 raster_settings):
         raw = dict(features_dc=features_dc, features_rest=_empty_to_none(features_rest), scaling=scaling_raw,
                    rotation=rotation_raw, opacity=opacity_raw)
-        st = rasterize_forward(raster_settings, xyz, None, raw=raw)
+        st = rasterize_forward(raster_settings, xyz, None, raw=raw, prepare_backward=any(ctx.needs_input_grad))
         if raster_settings.debug:
             torch.cuda.synchronize()
         ctx.raster_settings = raster_settings
@@ -410,14 +464,14 @@ class _RasterizeGaussians(torch.autograd.Function):
                     cov3D_precomp=_empty_to_none(cov3Ds_precomp))
         if s.debug:
             try:
-                st = rasterize_forward(s, means3D, opacities, **args)
+                st = rasterize_forward(s, means3D, opacities, prepare_backward=any(ctx.needs_input_grad), **args)
                 torch.cuda.synchronize()
             except Exception:
                 torch.save(dict(settings=tuple(s), means3D=means3D, opacities=opacities, **args), "snapshot_fw.dump")
                 print("\nAn error occured in forward. Please forward snapshot_fw.dump for debugging.")
                 raise
         else:
-            st = rasterize_forward(s, means3D, opacities, **args)
+            st = rasterize_forward(s, means3D, opacities, prepare_backward=any(ctx.needs_input_grad), **args)
         ctx.raster_settings = s
         ctx.state = st
         ctx.save_for_backward(means3D, sh, scales, rotations, cov3Ds_precomp)

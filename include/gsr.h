@@ -21,8 +21,8 @@
  *    aligned.
  *  - `stream` is a hipStream_t passed as void* (NULL = the null stream).
  *    Calls only enqueue work; none synchronises.  The one host read-back the
- *    pipeline needs (the list sizes, after gsr_bin_totals) is done by the
- *    caller.
+ *    pipeline needs (the list sizes, after gsr_preprocess_geometry) is done by
+ *    the caller.
  *  - Return value: 0 = success, negative = error (GSR_E_*); gsr_last_error()
  *    returns a message for the calling thread's last failure.
  *  - Floating tensors are fp32, contiguous.  Layouts follow the reference's
@@ -60,14 +60,15 @@ extern "C" {
 #define GSR_REC_CONIC_B 5
 #define GSR_REC_CONIC_C 6
 #define GSR_REC_OPACITY 7  /* ... and opacity: the float4 "conic_opacity"          */
-#define GSR_REC_R 8        /* colour after SH evaluation / colors_precomp          */
+#define GSR_REC_R 8        /* colour after SH evaluation / colors_precomp ...      */
 #define GSR_REC_G 9
 #define GSR_REC_B 10
-#define GSR_REC_DEPTH 11   /* view-space z                                        */
-#define GSR_REC_RECT_MIN 12 /* uint32: tile rect min, x | y << 16                  */
-#define GSR_REC_RECT_MAX 13 /* uint32: tile rect max (exclusive), x | y << 16      */
-#define GSR_REC_RADIUS 14   /* int32: screen radius in px, 0 = culled               */
-#define GSR_REC_CLAMPED 15  /* uint32: bit c set = colour channel c was clamped at 0 */
+#define GSR_REC_CLAMPED 11  /* ... and uint32: bit c set = colour channel c was clamped at 0
+                             * (words 8-11 are the colour kernel's, the rest the geometry kernel's) */
+#define GSR_REC_DEPTH 12    /* view-space z                                        */
+#define GSR_REC_RECT_MIN 13 /* uint32: tile rect min, x | y << 16                  */
+#define GSR_REC_RECT_MAX 14 /* uint32: tile rect max (exclusive), x | y << 16      */
+#define GSR_REC_RADIUS 15   /* int32: screen radius in px, 0 = culled               */
 
 int gsr_version(void);
 const char* gsr_last_error(void);
@@ -86,15 +87,49 @@ const char* gsr_last_error(void);
  * Outputs: records (P,16) words; radii (P) int32 (0 = not visible);
  * tiles_touched (P) uint32; depth_keys (P) uint32 = IEEE bits of view z for
  * visible Gaussians, 0xFFFFFFFF for culled ones; rects (P,2) uint32 = the tile
- * rectangle as in record words 12-13 (min, exclusive max; x | y << 16), zeros
- * for culled Gaussians: a compact copy for the binning kernels. */
+ * rectangle as in the record (min, exclusive max; x | y << 16), zeros for
+ * culled Gaussians; and what the binning starts from:
+ * sort_vals (P) uint64 = the Gaussian's index packed with its tile rectangle
+ * (bit widths chosen from P and the tile grid; the call fails if they exceed
+ * 64 bits, e.g. more than 2^24 Gaussians on a grid of more than 1024x1024
+ * tiles), the value the depth sort carries;
+ * totals[0..3] = { N = tile instances (sum of tiles_touched), E1 = supercell
+ * entries, E2 = cell entries, V = visible Gaussians }, which the caller reads
+ * back (the pipeline's one host read-back; it can overlap gsr_bin_sort) to size
+ * gsr_bin_lists.  totals has gsr_totals_words(P) words (the rest is the call's
+ * scratch) and is 16-byte aligned.
+ *
+ * The stage is two kernels, available separately so that a host can overlap
+ * them: gsr_preprocess_geometry produces everything except record words 8-11
+ * and is all the binning waits for; gsr_preprocess_color (SH -> RGB: 4/5 of the
+ * stage's input bytes) is only needed by gsr_blend_fwd and may run on another
+ * stream beside the depth sort.  gsr_preprocess_fwd runs both on one stream.
+ * `raw` != 0: scales, rotations, opacities are the model's RAW parameters and
+ * exp / normalize / sigmoid are applied in the kernel (see the raw variants). */
+size_t gsr_totals_words(int P);
+int gsr_preprocess_geometry(int P, int raw, const float* means3D, const float* scales,
+                            float scale_modifier, const float* rotations, const float* opacities,
+                            const float* cov3D_precomp, const float* viewmatrix,
+                            const float* projmatrix, int W, int H, float tanfovx, float tanfovy,
+                            uint32_t* records, int32_t* radii, uint32_t* tiles_touched,
+                            uint32_t* depth_keys, uint32_t* rects, uint64_t* sort_vals,
+                            uint32_t* totals, void* stream);
+/* shs_rest / n_rest: NULL / 0, or the model's _features_rest (P,n_rest,3) with shs =
+ * _features_dc (P,1,3) and M = 1 + n_rest (scene/gaussian_model.py:108-111).
+ * max_blocks > 0 caps the number of workgroups (the kernel strides over the Gaussians), for a
+ * host that runs it beside the binning and wants it to leave wave slots free; 0 = no cap. */
+int gsr_preprocess_color(int P, int D, int M, const float* means3D, const float* shs,
+                         const float* shs_rest, int n_rest, const float* colors_precomp,
+                         const float* campos, const int32_t* radii, uint32_t* records,
+                         int max_blocks, void* stream);
 int gsr_preprocess_fwd(int P, int D, int M, const float* means3D, const float* scales,
                        float scale_modifier, const float* rotations, const float* opacities,
                        const float* shs, const float* colors_precomp, const float* cov3D_precomp,
                        const float* viewmatrix, const float* projmatrix, const float* campos,
                        int W, int H, float tanfovx, float tanfovy, int prefiltered,
                        uint32_t* records, int32_t* radii, uint32_t* tiles_touched,
-                       uint32_t* depth_keys, uint32_t* rects, void* stream);
+                       uint32_t* depth_keys, uint32_t* rects, uint64_t* sort_vals,
+                       uint32_t* totals, void* stream);
 
 /* GaussianRasterizer.markVisible of the module (never called by the
  * reference's Python): present[i] = view-space z > 0.2. */
@@ -112,19 +147,9 @@ int gsr_mark_visible(int P, const float* means3D, const float* viewmatrix, uint8
  * stable, so the lists equal the 64-bit sort's.
  *
  * No index is ever dereferenced on the way: the depth sort carries, as its
- * 64-bit value, the Gaussian's index packed with its tile rectangle (bit
- * widths chosen from P and the tile grid; gsr_bin_totals fails if they exceed
- * 64 bits, e.g. more than 2^24 Gaussians on a grid of more than 1024x1024 tiles).
- *
- * gsr_bin_totals: totals[0..3] = { N = tile instances (sum of tiles_touched),
- * E1 = supercell entries, E2 = cell entries, V = visible Gaussians }, from the
- * rectangles alone, and sort_vals (P) uint64 = the packed (index, rectangle)
- * words.  The caller reads the four totals back (the pipeline's one host
- * read-back; it can overlap gsr_bin_sort) to size gsr_bin_lists.  totals has
- * GSR_TOTALS_WORDS words (the rest is the call's scratch), 16-byte aligned. */
-#define GSR_TOTALS_WORDS (4 + 4 * 256)
-int gsr_bin_totals(int P, int W, int H, const uint32_t* rects, uint32_t* totals,
-                   uint64_t* sort_vals, void* stream);
+ * 64-bit value, the Gaussian's index packed with its tile rectangle
+ * (sort_vals of stage 1), and that word is what the partitions read.
+ * V, N, E1, E2 below are the totals of stage 1, read back by the caller. */
 
 /* gsr_bin_sort: sorted_vals (P) uint64 = sort_vals ordered by ascending depth
  * key, ties by ascending index (stable); the V visible ones come first. */
@@ -134,7 +159,7 @@ int gsr_bin_sort(int P, const uint32_t* depth_keys, const uint64_t* sort_vals,
 
 /* gsr_bin_lists: point_list (N) uint32 = Gaussian index per sorted instance;
  * ranges (tiles,2) uint32 = [start,end) into point_list per tile, (0,0) for
- * empty tiles.  V, N, E1, E2 are the values gsr_bin_totals produced.
+ * empty tiles.
  * tile_ids_sorted (N) uint32 is optional (may be NULL): the tile id of each
  * sorted instance, from which the module's 64-bit sort keys are
  * (tile << 32) | depth_key[point_list]. */
@@ -201,7 +226,7 @@ int gsr_preprocess_fwd_raw(int P, int D, int n_rest, const float* xyz, const flo
                            const float* viewmatrix, const float* projmatrix, const float* campos,
                            int W, int H, float tanfovx, float tanfovy, uint32_t* records,
                            int32_t* radii, uint32_t* tiles_touched, uint32_t* depth_keys,
-                           uint32_t* rects, void* stream);
+                           uint32_t* rects, uint64_t* sort_vals, uint32_t* totals, void* stream);
 int gsr_preprocess_bwd_raw(int P, int D, int n_rest, const float* xyz, const float* scaling_raw,
                            float scale_modifier, const float* rotation_raw, const float* opacity_raw,
                            const float* features_dc, const float* features_rest,

@@ -19,6 +19,8 @@
 #define GSR_TILE_X 16
 #define GSR_TILE_Y 16
 #define GSR_TILE_PIXELS (GSR_TILE_X * GSR_TILE_Y)
+/* Side, in tiles, of the supercells (and width of the cells) of the binning's range partitions. */
+#define GSR_SUPERCELL 16
 
 /* A Gaussian whose view-space depth is <= this is culled. [UPSTREAM] */
 #define GSR_NEAR_CULL 0.2f
