@@ -205,7 +205,7 @@ struct GeoArgs {
   float scale_modifier, tanfovx, tanfovy;
   gsr::Pack pack;
   uint32_t* records; int32_t* radii; uint32_t* tiles_touched; uint32_t* depth_keys; uint32_t* rects;
-  unsigned long long* sort_vals; uint32_t* partials;
+  unsigned long long* sort_vals; uint32_t* partials; uint8_t* visible;
 };
 
 __device__ __forceinline__ uint32_t wave_sum_u32(uint32_t v) {
@@ -282,6 +282,7 @@ __global__ void __launch_bounds__(kBlock) preprocess_geometry_kernel(GeoArgs a) 
       }
     }
     uint4* rec = reinterpret_cast<uint4*>(a.records) + (size_t)i * 4;
+    if (a.visible) a.visible[i] = vis ? 1 : 0;
     if (!vis) {
       a.radii[i] = 0;
       a.tiles_touched[i] = 0;
@@ -664,7 +665,7 @@ extern "C" int gsr_preprocess_geometry(int P, int raw, const float* means3D, con
                                        const float* viewmatrix, const float* projmatrix, int W, int H, float tanfovx,
                                        float tanfovy, uint32_t* records, int32_t* radii, uint32_t* tiles_touched,
                                        uint32_t* depth_keys, uint32_t* rects, uint64_t* sort_vals, uint32_t* totals,
-                                       void* stream) {
+                                       uint8_t* visible, void* stream) {
   GSR_REQUIRE(P >= 0 && W > 0 && H > 0, "preprocess_geometry: bad sizes P=%d W=%d H=%d", P, W, H);
   GSR_REQUIRE(totals && ((uintptr_t)totals & 15) == 0, "preprocess_geometry: totals must be non-null and 16-byte aligned");
   hipStream_t st = (hipStream_t)stream;
@@ -680,7 +681,7 @@ extern "C" int gsr_preprocess_geometry(int P, int raw, const float* means3D, con
               P, W, H);
   GeoArgs a{raw, P, W, H, means3D, scales, rotations, opacities, cov3D_precomp, viewmatrix, projmatrix,
             scale_modifier, tanfovx, tanfovy, pack, records, radii, tiles_touched, depth_keys, rects,
-            (unsigned long long*)sort_vals, totals + 4};
+            (unsigned long long*)sort_vals, totals + 4, visible};
   const int blocks = gsr::div_up(P, kBlock);
   hipLaunchKernelGGL(preprocess_geometry_kernel, dim3(blocks), dim3(kBlock), 0, st, a);
   int rc = gsr::check_launch("preprocess_geometry");
@@ -726,7 +727,7 @@ extern "C" int gsr_preprocess_fwd(int P, int D, int M, const float* means3D, con
   (void)prefiltered;
   int rc = gsr_preprocess_geometry(P, 0, means3D, scales, scale_modifier, rotations, opacities, cov3D_precomp,
                                    viewmatrix, projmatrix, W, H, tanfovx, tanfovy, records, radii, tiles_touched,
-                                   depth_keys, rects, sort_vals, totals, stream);
+                                   depth_keys, rects, sort_vals, totals, nullptr, stream);
   if (rc) return rc;
   return gsr_preprocess_color(P, D, M, means3D, shs, nullptr, 0, colors_precomp, campos, radii, records, 0, stream);
 }
@@ -793,7 +794,7 @@ extern "C" int gsr_preprocess_fwd_raw(int P, int D, int n_rest, const float* xyz
   GSR_REQUIRE(P <= 0 || (scaling_raw && rotation_raw && features_dc), "preprocess_fwd_raw: null input");
   int rc = gsr_preprocess_geometry(P, 1, xyz, scaling_raw, scale_modifier, rotation_raw, opacity_raw, nullptr,
                                    viewmatrix, projmatrix, W, H, tanfovx, tanfovy, records, radii, tiles_touched,
-                                   depth_keys, rects, sort_vals, totals, stream);
+                                   depth_keys, rects, sort_vals, totals, nullptr, stream);
   if (rc) return rc;
   // with no rest tensor the dc tensor alone is a (P,1,3) shs tensor
   return gsr_preprocess_color(P, D, 1 + n_rest, xyz, features_dc, n_rest > 0 ? features_rest : nullptr, n_rest, nullptr,

@@ -55,7 +55,7 @@ def _load():
     lib.gsr_totals_words.restype = C.c_size_t
     lib.gsr_totals_words.argtypes = [ci]
     lib.gsr_preprocess_geometry.argtypes = [ci, ci, vp, vp, cf, vp, vp, vp, vp, vp, ci, ci, cf, cf,
-                                            vp, vp, vp, vp, vp, vp, vp, vp]
+                                            vp, vp, vp, vp, vp, vp, vp, vp, vp]
     lib.gsr_preprocess_color.argtypes = [ci, ci, ci, vp, vp, vp, ci, vp, vp, vp, vp, ci, vp]
     lib.gsr_preprocess_fwd.argtypes = [ci, ci, ci, vp, vp, cf, vp, vp, vp, vp, vp, vp, vp, vp, ci, ci, cf, cf, ci,
                                        vp, vp, vp, vp, vp, vp, vp, vp]
@@ -180,7 +180,7 @@ class ForwardState:
     """Everything the forward leaves behind: op outputs, what backward needs,
     and the intermediate buffers the parity tests inspect."""
     __slots__ = ("P", "M", "D", "W", "H", "records", "radii", "tiles_touched", "depth_keys", "sorted_vals", "rect_words",
-                 "num_rendered", "num_visible", "dsplat", "point_list", "ranges", "tile_ids_sorted", "color", "final_T", "n_contrib",
+                 "num_rendered", "num_visible", "dsplat", "visible", "point_list", "ranges", "tile_ids_sorted", "color", "final_T", "n_contrib",
                  "view", "proj", "campos", "bg")
 
     # views into the 64-byte records, named as the oracle names them
@@ -244,6 +244,7 @@ def rasterize_forward(s: GaussianRasterizationSettings, means3D, opacities, shs=
     st.depth_keys = torch.empty((P,), **u32)
     st.sorted_vals = torch.empty((P,), dtype=torch.int64, device=dev)   # packed (index, rectangle), front to back
     st.rect_words = torch.empty((P, 2), **u32)
+    st.visible = torch.empty((P,), dtype=torch.bool, device=dev)      # radii > 0, written by the geometry kernel
     gx, gy = (W + TILE - 1) // TILE, (H + TILE - 1) // TILE
     st.ranges = torch.empty((gx * gy, 2), **u32)
     st.color = torch.empty((3, H, W), dtype=torch.float32, device=dev)
@@ -270,7 +271,7 @@ def rasterize_forward(s: GaussianRasterizationSettings, means3D, opacities, shs=
             col = (_ptr(shs), None, 0, _ptr(colors_precomp))
         _run("preprocess_geometry", _lib.gsr_preprocess_geometry, P, *geo, _ptr(st.view), _ptr(st.proj), W, H,
              float(s.tanfovx), float(s.tanfovy), _ptr(st.records), _ptr(st.radii), _ptr(st.tiles_touched),
-             _ptr(st.depth_keys), _ptr(st.rect_words), _ptr(sort_vals), _ptr(totals), stream)
+             _ptr(st.depth_keys), _ptr(st.rect_words), _ptr(sort_vals), _ptr(totals), _ptr(st.visible), stream)
 
         def color_pass():
             _run("preprocess_color", _lib.gsr_preprocess_color, P, st.D, st.M, _ptr(means3D), col[0], col[1], col[2],
@@ -426,12 +427,15 @@ class _RasterizeGaussiansRaw(torch.autograd.Function):
         ctx.raster_settings = raster_settings
         ctx.state = st
         ctx.save_for_backward(xyz, features_dc, features_rest, opacity_raw, scaling_raw, rotation_raw)
-        ctx.mark_non_differentiable(st.radii)
-        return st.color, st.radii
+        ctx.mark_non_differentiable(st.radii, st.visible)
+        ctx.set_materialize_grads(False)        # no zero tensors for the integer outputs' "gradients"
+        return st.color, st.radii, st.visible
 
     @staticmethod
-    def backward(ctx, grad_out_color, _grad_radii):
+    def backward(ctx, grad_out_color, _grad_radii, _grad_visible):
         xyz, features_dc, features_rest, opacity_raw, scaling_raw, rotation_raw = ctx.saved_tensors
+        if grad_out_color is None:
+            grad_out_color = torch.zeros_like(ctx.state.color)
         raw = dict(features_dc=features_dc, features_rest=_empty_to_none(features_rest), scaling=scaling_raw,
                    rotation=rotation_raw, opacity=opacity_raw)
         g = rasterize_backward_raw(ctx.raster_settings, ctx.state, grad_out_color, xyz, raw)
@@ -443,7 +447,7 @@ class _RasterizeGaussiansRaw(torch.autograd.Function):
 
 def rasterize_gaussians_raw(xyz, means2D, features_dc, features_rest, opacity_raw, scaling_raw, rotation_raw,
                             raster_settings):
-    """(color, radii) from raw model parameters; an extension, not part of the reference's API."""
+    """(color, radii, radii > 0) from raw model parameters; an extension, not part of the reference's API."""
     if features_rest is None:
         features_rest = torch.Tensor([])
     return _RasterizeGaussiansRaw.apply(xyz, means2D, features_dc, features_rest, opacity_raw, scaling_raw,
@@ -476,11 +480,14 @@ class _RasterizeGaussians(torch.autograd.Function):
         ctx.state = st
         ctx.save_for_backward(means3D, sh, scales, rotations, cov3Ds_precomp)
         ctx.mark_non_differentiable(st.radii)
+        ctx.set_materialize_grads(False)        # no zero tensor for the radii's "gradient"
         return st.color, st.radii
 
     @staticmethod
     def backward(ctx, grad_out_color, _grad_radii):
         s, st = ctx.raster_settings, ctx.state
+        if grad_out_color is None:
+            grad_out_color = torch.zeros_like(st.color)
         means3D, sh, scales, rotations, cov3Ds_precomp = ctx.saved_tensors
         kw = dict(shs=_empty_to_none(sh), scales=_empty_to_none(scales), rotations=_empty_to_none(rotations),
                   cov3D_precomp=_empty_to_none(cov3Ds_precomp))

@@ -35,10 +35,10 @@ def render(viewpoint_camera, pc, pipe: PipelineParams, bg_color: torch.Tensor, s
     """Returns {"render", "viewspace_points", "visibility_filter", "radii"}.
     ``bg_color`` must be on the GPU, as in the reference (:22)."""
     xyz = pc.get_xyz
-    # gradient sink for the 2D means (:26-30); the rasterizer deposits (d/dx, d/dy, 0) in its .grad
-    screenspace_points = torch.zeros_like(xyz, requires_grad=True) + 0
-    if screenspace_points.requires_grad:
-        screenspace_points.retain_grad()
+    # gradient sink for the 2D means (:26-30); the rasterizer deposits (d/dx, d/dy, 0) in its .grad.
+    # The reference writes `zeros_like(...) + 0` and retain_grad(); a leaf that requires grad is the
+    # same sink without the extra add kernel and without the copy retain_grad makes in backward.
+    screenspace_points = torch.zeros_like(xyz, requires_grad=True)
 
     settings = GaussianRasterizationSettings(
         image_height=int(viewpoint_camera.image_height), image_width=int(viewpoint_camera.image_width),
@@ -48,9 +48,9 @@ def render(viewpoint_camera, pc, pipe: PipelineParams, bg_color: torch.Tensor, s
         campos=viewpoint_camera.camera_center, prefiltered=False, debug=pipe.debug)
     if (pipe.fused_activations and override_color is None and not pipe.convert_SHs_python
             and not pipe.compute_cov3D_python and hasattr(pc, "_features_rest")):
-        image, radii = rasterize_gaussians_raw(xyz, screenspace_points, pc._features_dc, pc._features_rest,
-                                               pc._opacity, pc._scaling, pc._rotation, settings)
-        return {"render": image, "viewspace_points": screenspace_points, "visibility_filter": radii > 0,
+        image, radii, visible = rasterize_gaussians_raw(xyz, screenspace_points, pc._features_dc, pc._features_rest,
+                                                        pc._opacity, pc._scaling, pc._rotation, settings)
+        return {"render": image, "viewspace_points": screenspace_points, "visibility_filter": visible,
                 "radii": radii}
     rasterizer = GaussianRasterizer(raster_settings=settings)
 

@@ -105,7 +105,9 @@ const char* gsr_last_error(void);
  * stage's input bytes) is only needed by gsr_blend_fwd and may run on another
  * stream beside the depth sort.  gsr_preprocess_fwd runs both on one stream.
  * `raw` != 0: scales, rotations, opacities are the model's RAW parameters and
- * exp / normalize / sigmoid are applied in the kernel (see the raw variants). */
+ * exp / normalize / sigmoid are applied in the kernel (see the raw variants).
+ * visible (P) uint8, optional (may be NULL): radii > 0, the `visibility_filter`
+ * render() returns (gaussian_renderer/__init__.py:99). */
 size_t gsr_totals_words(int P);
 int gsr_preprocess_geometry(int P, int raw, const float* means3D, const float* scales,
                             float scale_modifier, const float* rotations, const float* opacities,
@@ -113,7 +115,7 @@ int gsr_preprocess_geometry(int P, int raw, const float* means3D, const float* s
                             const float* projmatrix, int W, int H, float tanfovx, float tanfovy,
                             uint32_t* records, int32_t* radii, uint32_t* tiles_touched,
                             uint32_t* depth_keys, uint32_t* rects, uint64_t* sort_vals,
-                            uint32_t* totals, void* stream);
+                            uint32_t* totals, uint8_t* visible, void* stream);
 /* shs_rest / n_rest: NULL / 0, or the model's _features_rest (P,n_rest,3) with shs =
  * _features_dc (P,1,3) and M = 1 + n_rest (scene/gaussian_model.py:108-111).
  * max_blocks > 0 caps the number of workgroups (the kernel strides over the Gaussians), for a
