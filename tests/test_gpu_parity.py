@@ -43,6 +43,12 @@ CASES = {
     "deg1_close_camera": (6_000, 320, 320, 1, 16, (0.0, 0.0, 0.0), 1.0, dict(distance=1.6, scale_mult=2.0)),
     "skewed_hot_tiles": (30_000, 320, 192, 3, 16, (0.1, 0.1, 0.1), 1.0, dict(skew_fraction=0.5)),
     "low_opacity_no_termination": (8_000, 256, 256, 3, 16, (0.0, 0.0, 0.0), 1.0, dict(opacity_const=0.1)),
+    # binning extremes: rectangles that span every supercell, lists far longer than a partition piece,
+    # a grid of 135 supercells with partial ones at both edges, a one-tile image
+    "screen_filling_splats_1080p": (400, 1920, 1080, 0, 1, (0.0, 0.0, 0.0), 1.0, dict(scale_mult=6.0)),
+    "uhd_3840x2160": (20_000, 3840, 2160, 1, 4, (0.0, 0.0, 0.0), 1.0, {}),
+    "one_hot_tile": (12_000, 96, 64, 0, 1, (0.0, 0.0, 0.0), 1.0, dict(skew_fraction=1.0, distance=30.0)),
+    "single_tile_image": (500, 16, 16, 0, 1, (0.3, 0.3, 0.3), 1.0, {}),
 }
 
 
