@@ -57,8 +57,7 @@ def algorithmic_bytes(P, N, W, H, M=16):
     Gaussian."""
     b_in = 44 + 12 * M
     return {
-        "preprocess_geometry": P * (44 + 68),          # B_in + 80 in all, split over the stage's two kernels
-        "preprocess_color": P * (12 * M + 12),
+        "preprocess_fwd": P * (12 * M + 44 + 80),
         "blend_fwd": 40 * N + 20 * W * H,
         "blend_bwd": 40 * N + 32 * W * H + 36 * P,
         "preprocess_bwd": P * (b_in + 80 + 36 + b_in + 12),

@@ -78,13 +78,20 @@ __device__ __forceinline__ uint32_t wave_sum(uint32_t v) {
 }
 
 // Sums the per-block partial records the preprocess geometry kernel leaves behind.
-__global__ void __launch_bounds__(kBlock) totals_final_kernel(int blocks, const uint32_t* __restrict__ partials,
-                                                              uint32_t* __restrict__ totals) {
-  __shared__ uint32_t s_part[4][4];
+__global__ void __launch_bounds__(kScanBlock) totals_final_kernel(int blocks, const uint32_t* __restrict__ partials,
+                                                                  uint32_t* __restrict__ totals) {
+  __shared__ uint32_t s_part[kScanBlock / 64][4];
   uint32_t acc[4] = {0u, 0u, 0u, 0u};
-  for (int b = threadIdx.x; b < blocks; b += kBlock) {
-    const uint4 p = reinterpret_cast<const uint4*>(partials)[b];
-    acc[0] += p.x; acc[1] += p.y; acc[2] += p.z; acc[3] += p.w;
+  // four independent 16-byte loads per thread and round
+  for (int b0 = threadIdx.x; b0 < blocks; b0 += 4 * kScanBlock) {
+    uint4 p[4];
+#pragma unroll
+    for (int k = 0; k < 4; k++) {
+      const int b = b0 + k * kScanBlock;
+      p[k] = b < blocks ? reinterpret_cast<const uint4*>(partials)[b] : make_uint4(0u, 0u, 0u, 0u);
+    }
+#pragma unroll
+    for (int k = 0; k < 4; k++) { acc[0] += p[k].x; acc[1] += p[k].y; acc[2] += p[k].z; acc[3] += p[k].w; }
   }
   const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
 #pragma unroll
@@ -93,8 +100,12 @@ __global__ void __launch_bounds__(kBlock) totals_final_kernel(int blocks, const 
     if (lane == 0) s_part[wave][k] = acc[k];
   }
   __syncthreads();
-  if (threadIdx.x < 4)
-    totals[threadIdx.x] = s_part[0][threadIdx.x] + s_part[1][threadIdx.x] + s_part[2][threadIdx.x] + s_part[3][threadIdx.x];
+  if (threadIdx.x < 4) {
+    uint32_t t = 0;
+#pragma unroll
+    for (int w = 0; w < kScanBlock / 64; w++) t += s_part[w][threadIdx.x];
+    totals[threadIdx.x] = t;
+  }
 }
 
 // ---------------------------------------------------------------------------
@@ -491,7 +502,7 @@ ListsLayout lists_layout(uint32_t V, uint32_t E1, uint32_t E2, const Grid& g) {
 }  // namespace
 
 int gsr::launch_totals_final(int blocks, const uint32_t* partials, uint32_t* totals, hipStream_t stream) {
-  hipLaunchKernelGGL(totals_final_kernel, dim3(1), dim3(kBlock), 0, stream, blocks, partials, totals);
+  hipLaunchKernelGGL(totals_final_kernel, dim3(1), dim3(kScanBlock), 0, stream, blocks, partials, totals);
   return gsr::check_launch("totals");
 }
 

@@ -195,13 +195,11 @@ __device__ __forceinline__ float quat_norm(const float* q) {
   return fmaxf(sqrtf(q[0] * q[0] + q[1] * q[1] + q[2] * q[2] + q[3] * q[3]), 1e-12f);
 }
 
-// The forward runs as two kernels so that a host can overlap them: the geometry kernel produces
-// everything the binning needs (and is all the depth sort waits for), the colour kernel streams
-// the SH coefficients (4/5 of the input bytes) and is only needed by the blend.
-struct GeoArgs {
-  int raw, P, W, H;
+struct FwdArgs {
+  int raw, n_rest, P, M, W, H;
   const float* means3D; const float* scales; const float* rotations; const float* opacities;
-  const float* cov3D_precomp; const float* view; const float* proj;
+  const float* shs; const float* shs_rest; const float* colors_precomp;
+  const float* cov3D_precomp; const float* view; const float* proj; const float* campos;
   float scale_modifier, tanfovx, tanfovy;
   gsr::Pack pack;
   uint32_t* records; int32_t* radii; uint32_t* tiles_touched; uint32_t* depth_keys; uint32_t* rects;
@@ -214,7 +212,8 @@ __device__ __forceinline__ uint32_t wave_sum_u32(uint32_t v) {
   return v;
 }
 
-__global__ void __launch_bounds__(kBlock) preprocess_geometry_kernel(GeoArgs a) {
+template <int D>
+__global__ void __launch_bounds__(kBlock) preprocess_fwd_kernel(FwdArgs a) {
   __shared__ uint32_t s_part[kBlock / 64][4];
   const int i = blockIdx.x * kBlock + threadIdx.x;
   bool vis = false;
@@ -301,6 +300,35 @@ __global__ void __launch_bounds__(kBlock) preprocess_geometry_kernel(GeoArgs a) 
       rec[1] = make_uint4(__float_as_uint(conA), __float_as_uint(conB), __float_as_uint(conC),
                           __float_as_uint(opacity));
       rec[3] = make_uint4(__float_as_uint(depth), rmin, rmax, (uint32_t)radius);
+
+      // colour: SH -> RGB with +0.5 and clamp at 0, or the colour handed in
+      float r = 0.f, g = 0.f, b = 0.f;
+      unsigned clamped = 0;
+      if (a.colors_precomp) {
+        r = a.colors_precomp[3 * (size_t)i];
+        g = a.colors_precomp[3 * (size_t)i + 1];
+        b = a.colors_precomp[3 * (size_t)i + 2];
+      } else {
+        // gaussian_renderer/__init__.py:75-78
+        float dx = px3 - a.campos[0], dy = py3 - a.campos[1], dz = pz3 - a.campos[2];
+        const float len = sqrtf(dx * dx + dy * dy + dz * dz);
+        dx = dx / len; dy = dy / len; dz = dz / len;
+        constexpr int N = (D + 1) * (D + 1);
+        float bas[N], sh[3 * N], col[3];
+        sh_basis<D>(dx, dy, dz, bas);
+        load_sh<D>(a.shs, a.shs_rest ? a.shs_rest + (size_t)i * (a.n_rest * 3) : nullptr, a.M, i, sh);
+#pragma unroll
+        for (int ch = 0; ch < 3; ch++) {
+          float acc = bas[0] * sh[ch];
+#pragma unroll
+          for (int k = 1; k < N; k++) acc = acc + bas[k] * sh[3 * k + ch];
+          acc = acc + GSR_SH_OFFSET;
+          if (acc < 0.0f) clamped |= 1u << ch;
+          col[ch] = fmaxf(acc, 0.0f);
+        }
+        r = col[0]; g = col[1]; b = col[2];
+      }
+      rec[2] = make_uint4(__float_as_uint(r), __float_as_uint(g), __float_as_uint(b), clamped);
     }
   }
   // list sizes of the binning (tile instances, supercell entries, cell entries, visible Gaussians):
@@ -323,50 +351,6 @@ __global__ void __launch_bounds__(kBlock) preprocess_geometry_kernel(GeoArgs a) 
 #pragma unroll
     for (int w = 0; w < kBlock / 64; w++) t += s_part[w][threadIdx.x];
     a.partials[4 * blockIdx.x + threadIdx.x] = t;
-  }
-}
-
-struct ColorArgs {
-  int P, M, n_rest;
-  const float* means3D; const float* shs; const float* shs_rest; const float* colors_precomp; const float* campos;
-  const int32_t* radii; uint32_t* records;
-};
-
-template <int D>
-__global__ void __launch_bounds__(kBlock) preprocess_color_kernel(ColorArgs a) {
-  // grid-stride: a host that runs this kernel beside others launches few blocks, so that it
-  // never occupies every wave slot of the chip
-  for (int i = blockIdx.x * kBlock + threadIdx.x; i < a.P; i += gridDim.x * kBlock) {
-  if (a.radii[i] <= 0) continue;
-  float r = 0.f, g = 0.f, b = 0.f;
-  unsigned clamped = 0;
-  if (a.colors_precomp) {
-    r = a.colors_precomp[3 * (size_t)i];
-    g = a.colors_precomp[3 * (size_t)i + 1];
-    b = a.colors_precomp[3 * (size_t)i + 2];
-  } else {
-    // gaussian_renderer/__init__.py:75-78
-    const float px3 = a.means3D[3 * i], py3 = a.means3D[3 * i + 1], pz3 = a.means3D[3 * i + 2];
-    float dx = px3 - a.campos[0], dy = py3 - a.campos[1], dz = pz3 - a.campos[2];
-    const float len = sqrtf(dx * dx + dy * dy + dz * dz);
-    dx = dx / len; dy = dy / len; dz = dz / len;
-    constexpr int N = (D + 1) * (D + 1);
-    float bas[N], sh[3 * N], col[3];
-    sh_basis<D>(dx, dy, dz, bas);
-    load_sh<D>(a.shs, a.shs_rest ? a.shs_rest + (size_t)i * (a.n_rest * 3) : nullptr, a.M, i, sh);
-#pragma unroll
-    for (int ch = 0; ch < 3; ch++) {
-      float acc = bas[0] * sh[ch];
-#pragma unroll
-      for (int k = 1; k < N; k++) acc = acc + bas[k] * sh[3 * k + ch];
-      acc = acc + GSR_SH_OFFSET;
-      if (acc < 0.0f) clamped |= 1u << ch;
-      col[ch] = fmaxf(acc, 0.0f);
-    }
-    r = col[0]; g = col[1]; b = col[2];
-  }
-  reinterpret_cast<uint4*>(a.records)[(size_t)i * 4 + 2] =
-      make_uint4(__float_as_uint(r), __float_as_uint(g), __float_as_uint(b), clamped);
   }
 }
 
@@ -660,61 +644,25 @@ __global__ void __launch_bounds__(kBlock, 4) preprocess_bwd_kernel(BwdArgs a) {
 
 extern "C" size_t gsr_totals_words(int P) { return 4 + 4 * (size_t)(P > 0 ? gsr::div_up(P, kBlock) : 0); }
 
-extern "C" int gsr_preprocess_geometry(int P, int raw, const float* means3D, const float* scales, float scale_modifier,
-                                       const float* rotations, const float* opacities, const float* cov3D_precomp,
-                                       const float* viewmatrix, const float* projmatrix, int W, int H, float tanfovx,
-                                       float tanfovy, uint32_t* records, int32_t* radii, uint32_t* tiles_touched,
-                                       uint32_t* depth_keys, uint32_t* rects, uint64_t* sort_vals, uint32_t* totals,
-                                       uint8_t* visible, void* stream) {
-  GSR_REQUIRE(P >= 0 && W > 0 && H > 0, "preprocess_geometry: bad sizes P=%d W=%d H=%d", P, W, H);
-  GSR_REQUIRE(totals && ((uintptr_t)totals & 15) == 0, "preprocess_geometry: totals must be non-null and 16-byte aligned");
+namespace {
+
+int launch_preprocess_fwd(const char* who, FwdArgs a, int D, uint32_t* totals, void* stream) {
   hipStream_t st = (hipStream_t)stream;
-  if (P == 0) return gsr::launch_totals_final(0, totals + 4, totals, st);
-  GSR_REQUIRE(means3D && opacities && viewmatrix && projmatrix, "preprocess_geometry: null input");
-  GSR_REQUIRE(records && radii && tiles_touched && depth_keys && rects && sort_vals, "preprocess_geometry: null output");
-  GSR_REQUIRE(((scales != nullptr) && (rotations != nullptr)) != (cov3D_precomp != nullptr),
-              "preprocess_geometry: give exactly one of (scales, rotations) / cov3D_precomp");
-  GSR_REQUIRE(!(raw && cov3D_precomp), "preprocess_geometry: raw parameters and cov3D_precomp exclude each other");
-  GSR_REQUIRE(W <= 16 * 16 * 255 && H <= 16 * 16 * 255, "preprocess_geometry: image %dx%d too large", W, H);
-  const gsr::Pack pack = gsr::make_pack(P, gsr::div_up(W, GSR_TILE_X), gsr::div_up(H, GSR_TILE_Y));
-  GSR_REQUIRE(pack.bits() <= 64, "preprocess_geometry: %d Gaussians on a %dx%d image do not fit the 64-bit sort value",
-              P, W, H);
-  GeoArgs a{raw, P, W, H, means3D, scales, rotations, opacities, cov3D_precomp, viewmatrix, projmatrix,
-            scale_modifier, tanfovx, tanfovy, pack, records, radii, tiles_touched, depth_keys, rects,
-            (unsigned long long*)sort_vals, totals + 4, visible};
-  const int blocks = gsr::div_up(P, kBlock);
-  hipLaunchKernelGGL(preprocess_geometry_kernel, dim3(blocks), dim3(kBlock), 0, st, a);
-  int rc = gsr::check_launch("preprocess_geometry");
+  const int blocks = gsr::div_up(a.P, kBlock);
+  dim3 grid(blocks), block(kBlock);
+  a.partials = totals + 4;
+  switch (a.shs ? D : 0) {
+    case 0: hipLaunchKernelGGL(preprocess_fwd_kernel<0>, grid, block, 0, st, a); break;
+    case 1: hipLaunchKernelGGL(preprocess_fwd_kernel<1>, grid, block, 0, st, a); break;
+    case 2: hipLaunchKernelGGL(preprocess_fwd_kernel<2>, grid, block, 0, st, a); break;
+    default: hipLaunchKernelGGL(preprocess_fwd_kernel<3>, grid, block, 0, st, a); break;
+  }
+  int rc = gsr::check_launch(who);
   if (rc) return rc;
   return gsr::launch_totals_final(blocks, totals + 4, totals, st);
 }
 
-extern "C" int gsr_preprocess_color(int P, int D, int M, const float* means3D, const float* shs, const float* shs_rest,
-                                    int n_rest, const float* colors_precomp, const float* campos, const int32_t* radii,
-                                    uint32_t* records, int max_blocks, void* stream) {
-  GSR_REQUIRE(P >= 0, "preprocess_color: bad P");
-  if (P == 0) return GSR_OK;
-  GSR_REQUIRE(radii && records, "preprocess_color: null pointer");
-  GSR_REQUIRE((shs != nullptr) != (colors_precomp != nullptr), "preprocess_color: give exactly one of shs / colors_precomp");
-  GSR_REQUIRE(colors_precomp || (means3D && campos), "preprocess_color: null input");
-  GSR_REQUIRE(D >= 0 && D <= GSR_MAX_SH_DEGREE, "preprocess_color: SH degree %d unsupported (0..3)", D);
-  GSR_REQUIRE(!shs || M >= (D + 1) * (D + 1), "preprocess_color: M=%d too small for degree %d", M, D);
-  GSR_REQUIRE(!shs_rest || (shs && n_rest >= (D + 1) * (D + 1) - 1 && n_rest <= 15 && M == 1 + n_rest),
-              "preprocess_color: n_rest=%d does not hold degree %d", n_rest, D);
-  ColorArgs a{P, M, n_rest, means3D, shs, shs_rest, colors_precomp, campos, radii, records};
-  hipStream_t st = (hipStream_t)stream;
-  int blocks = gsr::div_up(P, kBlock);
-  if (max_blocks > 0 && blocks > max_blocks) blocks = max_blocks;
-  dim3 grid(blocks), block(kBlock);
-  const int d = shs ? D : 0;
-  switch (d) {
-    case 0: hipLaunchKernelGGL(preprocess_color_kernel<0>, grid, block, 0, st, a); break;
-    case 1: hipLaunchKernelGGL(preprocess_color_kernel<1>, grid, block, 0, st, a); break;
-    case 2: hipLaunchKernelGGL(preprocess_color_kernel<2>, grid, block, 0, st, a); break;
-    default: hipLaunchKernelGGL(preprocess_color_kernel<3>, grid, block, 0, st, a); break;
-  }
-  return gsr::check_launch("preprocess_color");
-}
+}  // namespace
 
 extern "C" int gsr_preprocess_fwd(int P, int D, int M, const float* means3D, const float* scales,
                                   float scale_modifier, const float* rotations, const float* opacities,
@@ -723,13 +671,25 @@ extern "C" int gsr_preprocess_fwd(int P, int D, int M, const float* means3D, con
                                   int W, int H, float tanfovx, float tanfovy, int prefiltered,
                                   uint32_t* records, int32_t* radii, uint32_t* tiles_touched,
                                   uint32_t* depth_keys, uint32_t* rects, uint64_t* sort_vals, uint32_t* totals,
-                                  void* stream) {
+                                  uint8_t* visible, void* stream) {
   (void)prefiltered;
-  int rc = gsr_preprocess_geometry(P, 0, means3D, scales, scale_modifier, rotations, opacities, cov3D_precomp,
-                                   viewmatrix, projmatrix, W, H, tanfovx, tanfovy, records, radii, tiles_touched,
-                                   depth_keys, rects, sort_vals, totals, nullptr, stream);
-  if (rc) return rc;
-  return gsr_preprocess_color(P, D, M, means3D, shs, nullptr, 0, colors_precomp, campos, radii, records, 0, stream);
+  GSR_REQUIRE(P >= 0 && W > 0 && H > 0, "preprocess_fwd: bad sizes P=%d W=%d H=%d", P, W, H);
+  GSR_REQUIRE(totals && ((uintptr_t)totals & 15) == 0, "preprocess_fwd: totals must be non-null and 16-byte aligned");
+  if (P == 0) return gsr::launch_totals_final(0, totals + 4, totals, (hipStream_t)stream);
+  GSR_REQUIRE(means3D && opacities && viewmatrix && projmatrix && campos, "preprocess_fwd: null input");
+  GSR_REQUIRE(records && radii && tiles_touched && depth_keys && rects && sort_vals, "preprocess_fwd: null output");
+  GSR_REQUIRE((shs != nullptr) != (colors_precomp != nullptr), "preprocess_fwd: give exactly one of shs / colors_precomp");
+  GSR_REQUIRE(((scales != nullptr) && (rotations != nullptr)) != (cov3D_precomp != nullptr),
+              "preprocess_fwd: give exactly one of (scales, rotations) / cov3D_precomp");
+  GSR_REQUIRE(D >= 0 && D <= GSR_MAX_SH_DEGREE, "preprocess_fwd: SH degree %d unsupported (0..3)", D);
+  GSR_REQUIRE(!shs || M >= (D + 1) * (D + 1), "preprocess_fwd: M=%d too small for degree %d", M, D);
+  GSR_REQUIRE(W <= 16 * 16 * 255 && H <= 16 * 16 * 255, "preprocess_fwd: image %dx%d too large", W, H);
+  const gsr::Pack pack = gsr::make_pack(P, gsr::div_up(W, GSR_TILE_X), gsr::div_up(H, GSR_TILE_Y));
+  GSR_REQUIRE(pack.bits() <= 64, "preprocess_fwd: %d Gaussians on a %dx%d image do not fit the 64-bit sort value", P, W, H);
+  FwdArgs a{0, 0, P, M, W, H, means3D, scales, rotations, opacities, shs, nullptr, colors_precomp, cov3D_precomp,
+            viewmatrix, projmatrix, campos, scale_modifier, tanfovx, tanfovy, pack, records, radii, tiles_touched,
+            depth_keys, rects, (unsigned long long*)sort_vals, nullptr, visible};
+  return launch_preprocess_fwd("preprocess_fwd", a, D, totals, stream);
 }
 
 extern "C" int gsr_mark_visible(int P, const float* means3D, const float* viewmatrix, uint8_t* present,
@@ -790,15 +750,26 @@ extern "C" int gsr_preprocess_fwd_raw(int P, int D, int n_rest, const float* xyz
                                       const float* viewmatrix, const float* projmatrix, const float* campos, int W,
                                       int H, float tanfovx, float tanfovy, uint32_t* records, int32_t* radii,
                                       uint32_t* tiles_touched, uint32_t* depth_keys, uint32_t* rects,
-                                      uint64_t* sort_vals, uint32_t* totals, void* stream) {
-  GSR_REQUIRE(P <= 0 || (scaling_raw && rotation_raw && features_dc), "preprocess_fwd_raw: null input");
-  int rc = gsr_preprocess_geometry(P, 1, xyz, scaling_raw, scale_modifier, rotation_raw, opacity_raw, nullptr,
-                                   viewmatrix, projmatrix, W, H, tanfovx, tanfovy, records, radii, tiles_touched,
-                                   depth_keys, rects, sort_vals, totals, nullptr, stream);
-  if (rc) return rc;
+                                      uint64_t* sort_vals, uint32_t* totals, uint8_t* visible, void* stream) {
+  GSR_REQUIRE(P >= 0 && W > 0 && H > 0, "preprocess_fwd_raw: bad sizes P=%d W=%d H=%d", P, W, H);
+  GSR_REQUIRE(totals && ((uintptr_t)totals & 15) == 0, "preprocess_fwd_raw: totals must be non-null and 16-byte aligned");
+  if (P == 0) return gsr::launch_totals_final(0, totals + 4, totals, (hipStream_t)stream);
+  GSR_REQUIRE(xyz && scaling_raw && rotation_raw && opacity_raw && features_dc && viewmatrix && projmatrix && campos,
+              "preprocess_fwd_raw: null input");
+  GSR_REQUIRE(records && radii && tiles_touched && depth_keys && rects && sort_vals, "preprocess_fwd_raw: null output");
+  GSR_REQUIRE(D >= 0 && D <= GSR_MAX_SH_DEGREE, "preprocess_fwd_raw: SH degree %d unsupported (0..3)", D);
+  GSR_REQUIRE(n_rest >= (D + 1) * (D + 1) - 1 && n_rest <= 15 && (n_rest == 0 || features_rest),
+              "preprocess_fwd_raw: n_rest=%d does not hold degree %d", n_rest, D);
+  GSR_REQUIRE(W <= 16 * 16 * 255 && H <= 16 * 16 * 255, "preprocess_fwd_raw: image %dx%d too large", W, H);
+  const gsr::Pack pack = gsr::make_pack(P, gsr::div_up(W, GSR_TILE_X), gsr::div_up(H, GSR_TILE_Y));
+  GSR_REQUIRE(pack.bits() <= 64, "preprocess_fwd_raw: %d Gaussians on a %dx%d image do not fit the 64-bit sort value", P,
+              W, H);
   // with no rest tensor the dc tensor alone is a (P,1,3) shs tensor
-  return gsr_preprocess_color(P, D, 1 + n_rest, xyz, features_dc, n_rest > 0 ? features_rest : nullptr, n_rest, nullptr,
-                              campos, radii, records, 0, stream);
+  FwdArgs a{1, n_rest, P, 1 + n_rest, W, H, xyz, scaling_raw, rotation_raw, opacity_raw, features_dc,
+            n_rest > 0 ? features_rest : nullptr, nullptr, nullptr, viewmatrix, projmatrix, campos, scale_modifier,
+            tanfovx, tanfovy, pack, records, radii, tiles_touched, depth_keys, rects, (unsigned long long*)sort_vals,
+            nullptr, visible};
+  return launch_preprocess_fwd("preprocess_fwd_raw", a, D, totals, stream);
 }
 
 extern "C" int gsr_preprocess_bwd_raw(int P, int D, int n_rest, const float* xyz, const float* scaling_raw,

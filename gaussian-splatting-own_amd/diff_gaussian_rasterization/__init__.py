@@ -33,11 +33,8 @@ _LIB_PATH = os.environ.get("GSR_HIP_LIB") or os.path.join(_HERE, "libgsr_hip.so"
 TILE = 16
 REC_WORDS = 16
 GRAD_WORDS = 16
-# GSR_NO_OVERLAP=1 keeps the colour kernel on the caller's stream (A/B runs, debugging)
+# GSR_NO_OVERLAP=1 clears the backward's accumulator on the caller's stream (A/B runs, debugging)
 _OVERLAP = os.environ.get("GSR_NO_OVERLAP", "0") in ("", "0")
-# workgroups of the overlapped colour kernel: one per CU leaves most wave slots to the binning
-_COLOR_BLOCKS = int(os.environ.get("GSR_COLOR_BLOCKS", "256"))
-_COLOR_AFTER_SORT = os.environ.get("GSR_COLOR_AFTER_SORT", "0") not in ("", "0")
 
 
 def _load():
@@ -54,11 +51,8 @@ def _load():
     vp, ci, cf = C.c_void_p, C.c_int, C.c_float
     lib.gsr_totals_words.restype = C.c_size_t
     lib.gsr_totals_words.argtypes = [ci]
-    lib.gsr_preprocess_geometry.argtypes = [ci, ci, vp, vp, cf, vp, vp, vp, vp, vp, ci, ci, cf, cf,
-                                            vp, vp, vp, vp, vp, vp, vp, vp, vp]
-    lib.gsr_preprocess_color.argtypes = [ci, ci, ci, vp, vp, vp, ci, vp, vp, vp, vp, ci, vp]
     lib.gsr_preprocess_fwd.argtypes = [ci, ci, ci, vp, vp, cf, vp, vp, vp, vp, vp, vp, vp, vp, ci, ci, cf, cf, ci,
-                                       vp, vp, vp, vp, vp, vp, vp, vp]
+                                       vp, vp, vp, vp, vp, vp, vp, vp, vp]
     lib.gsr_mark_visible.argtypes = [ci, vp, vp, vp, vp]
     u32 = C.c_uint32
     lib.gsr_bin_sort.argtypes = [ci, vp, vp, vp, vp, C.c_size_t, vp]
@@ -68,7 +62,7 @@ def _load():
     lib.gsr_preprocess_bwd.argtypes = [ci, ci, ci, vp, vp, cf, vp, vp, vp, vp, vp, vp, ci, ci, cf, cf, vp, vp,
                                        vp, vp, vp, vp, vp, vp, vp, vp, vp]
     lib.gsr_preprocess_fwd_raw.argtypes = [ci, ci, ci, vp, vp, cf, vp, vp, vp, vp, vp, vp, vp, ci, ci, cf, cf,
-                                           vp, vp, vp, vp, vp, vp, vp, vp]
+                                           vp, vp, vp, vp, vp, vp, vp, vp, vp]
     lib.gsr_preprocess_bwd_raw.argtypes = [ci, ci, ci, vp, vp, cf, vp, vp, vp, vp, vp, vp, vp, ci, ci, cf, cf,
                                            vp, vp, vp, vp, vp, vp, vp, vp, vp, vp]
     return lib
@@ -132,13 +126,12 @@ _side = {}
 
 
 def _side_stream(dev: torch.device) -> torch.cuda.Stream:
-    """The second stream (default priority) the colour kernel runs on, one per device."""
+    """A second stream (default priority) for work off the critical path, one per device."""
     key = dev.index if dev.index is not None else torch.cuda.current_device()
     st = _side.get(key)
     if st is None:
         st = _side[key] = torch.cuda.Stream(device=dev)
     return st
-
 
 
 def _pinned_totals(dev: torch.device) -> torch.Tensor:
@@ -244,7 +237,7 @@ def rasterize_forward(s: GaussianRasterizationSettings, means3D, opacities, shs=
     st.depth_keys = torch.empty((P,), **u32)
     st.sorted_vals = torch.empty((P,), dtype=torch.int64, device=dev)   # packed (index, rectangle), front to back
     st.rect_words = torch.empty((P, 2), **u32)
-    st.visible = torch.empty((P,), dtype=torch.bool, device=dev)      # radii > 0, written by the geometry kernel
+    st.visible = torch.empty((P,), dtype=torch.bool, device=dev)      # radii > 0, written by the preprocess kernel
     gx, gy = (W + TILE - 1) // TILE, (H + TILE - 1) // TILE
     st.ranges = torch.empty((gx * gy, 2), **u32)
     st.color = torch.empty((3, H, W), dtype=torch.float32, device=dev)
@@ -254,51 +247,35 @@ def rasterize_forward(s: GaussianRasterizationSettings, means3D, opacities, shs=
 
     st.dsplat = None
     N = E1 = E2 = V = 0
-    color_done = None
     if P > 0:
         totals = torch.empty((_lib.gsr_totals_words(P),), **u32)
         sort_vals = torch.empty((P,), dtype=torch.int64, device=dev)
+        outs = (_ptr(st.records), _ptr(st.radii), _ptr(st.tiles_touched), _ptr(st.depth_keys), _ptr(st.rect_words),
+                _ptr(sort_vals), _ptr(totals), _ptr(st.visible), stream)
         if raw is not None:
             r = {k: _f32(v, k) for k, v in raw.items()}
             n_rest = 0 if r["features_rest"] is None else r["features_rest"].shape[1]
             st.M = 1 + n_rest
-            geo = (1, _ptr(means3D), _ptr(r["scaling"]), float(s.scale_modifier), _ptr(r["rotation"]),
-                   _ptr(r["opacity"]), None)
-            col = (_ptr(r["features_dc"]), _ptr(r["features_rest"]), n_rest, None)
+            _run("preprocess_fwd", _lib.gsr_preprocess_fwd_raw, P, st.D, n_rest, _ptr(means3D), _ptr(r["scaling"]),
+                 float(s.scale_modifier), _ptr(r["rotation"]), _ptr(r["opacity"]), _ptr(r["features_dc"]),
+                 _ptr(r["features_rest"]), _ptr(st.view), _ptr(st.proj), _ptr(st.campos), W, H, float(s.tanfovx),
+                 float(s.tanfovy), *outs)
         else:
-            geo = (0, _ptr(means3D), _ptr(scales), float(s.scale_modifier), _ptr(rotations), _ptr(opacities),
-                   _ptr(cov3D_precomp))
-            col = (_ptr(shs), None, 0, _ptr(colors_precomp))
-        _run("preprocess_geometry", _lib.gsr_preprocess_geometry, P, *geo, _ptr(st.view), _ptr(st.proj), W, H,
-             float(s.tanfovx), float(s.tanfovy), _ptr(st.records), _ptr(st.radii), _ptr(st.tiles_touched),
-             _ptr(st.depth_keys), _ptr(st.rect_words), _ptr(sort_vals), _ptr(totals), _ptr(st.visible), stream)
+            _run("preprocess_fwd", _lib.gsr_preprocess_fwd, P, st.D, st.M, _ptr(means3D), _ptr(scales),
+                 float(s.scale_modifier), _ptr(rotations), _ptr(opacities), _ptr(shs), _ptr(colors_precomp),
+                 _ptr(cov3D_precomp), _ptr(st.view), _ptr(st.proj), _ptr(st.campos), W, H, float(s.tanfovx),
+                 float(s.tanfovy), int(bool(s.prefiltered)), *outs)
 
-        def color_pass():
-            _run("preprocess_color", _lib.gsr_preprocess_color, P, st.D, st.M, _ptr(means3D), col[0], col[1], col[2],
-                 col[3], _ptr(st.campos), _ptr(st.radii), _ptr(st.records), _COLOR_BLOCKS if _OVERLAP else 0, _stream())
-            if prepare_backward:
-                st.dsplat = torch.zeros((P, GRAD_WORDS), dtype=torch.float32, device=dev)
-
-        # SH -> RGB streams 4/5 of the stage's input bytes and only the blend needs it: it runs on a
-        # second stream beside the depth sort and the partitions, which are short dependent launches
-        # that leave HBM idle.  The backward's accumulator is cleared there too.
-        def overlapped_color_pass():
+        # The blend backward accumulates into a zeroed (P,16) buffer.  The depth sort and the
+        # partitions are short dependent launches that leave HBM idle: the fill runs beside them on
+        # a second stream.
+        if prepare_backward and _OVERLAP:
             main, side = torch.cuda.current_stream(dev), _side_stream(dev)
-            ready = torch.cuda.Event()
-            ready.record(main)
-            side.wait_event(ready)
             with torch.cuda.stream(side):
-                color_pass()
-                done = torch.cuda.Event()
-                done.record(side)
-            if st.dsplat is not None:
-                st.dsplat.record_stream(main)
-            return done
-
-        if not _OVERLAP:
-            color_pass()
-        elif not _COLOR_AFTER_SORT:
-            color_done = overlapped_color_pass()
+                st.dsplat = torch.zeros((P, GRAD_WORDS), dtype=torch.float32, device=dev)
+                cleared = torch.cuda.Event()
+                cleared.record(side)
+            st.dsplat.record_stream(main)
 
         # The list sizes go to the host (the pipeline's one read-back) while the GPU sorts by depth:
         # the copy is queued before the sort and the host waits for the copy alone.
@@ -310,8 +287,6 @@ def rasterize_forward(s: GaussianRasterizationSettings, means3D, opacities, shs=
         scratch = torch.empty((nb,), dtype=torch.uint8, device=dev)
         _run("bin_sort", _lib.gsr_bin_sort, P, _ptr(st.depth_keys), _ptr(sort_vals), _ptr(st.sorted_vals),
              _ptr(scratch), nb, stream)
-        if _OVERLAP and _COLOR_AFTER_SORT:
-            color_done = overlapped_color_pass()
         copied.synchronize()
         N, E1, E2, V = (int(v) & 0xFFFFFFFF for v in host.tolist())
     st.num_rendered, st.num_visible = N, V
@@ -322,8 +297,8 @@ def rasterize_forward(s: GaussianRasterizationSettings, means3D, opacities, shs=
     scratch = torch.empty((nb,), dtype=torch.uint8, device=dev)
     _run("bin_lists", _lib.gsr_bin_lists, P, V, N, E1, E2, W, H, _ptr(st.sorted_vals), _ptr(st.point_list),
          _ptr(st.ranges), _ptr(st.tile_ids_sorted), _ptr(scratch), nb, stream)
-    if color_done is not None:
-        torch.cuda.current_stream(dev).wait_event(color_done)
+    if st.dsplat is not None:
+        torch.cuda.current_stream(dev).wait_event(cleared)
     _run("blend_fwd", _lib.gsr_blend_fwd, W, H, _ptr(st.ranges), _ptr(st.point_list), _ptr(st.records), _ptr(st.bg),
                               _ptr(st.color), _ptr(st.final_T), _ptr(st.n_contrib), stream)
     st.point_list = st.point_list[:N]

@@ -63,8 +63,7 @@ extern "C" {
 #define GSR_REC_R 8        /* colour after SH evaluation / colors_precomp ...      */
 #define GSR_REC_G 9
 #define GSR_REC_B 10
-#define GSR_REC_CLAMPED 11  /* ... and uint32: bit c set = colour channel c was clamped at 0
-                             * (words 8-11 are the colour kernel's, the rest the geometry kernel's) */
+#define GSR_REC_CLAMPED 11  /* ... and uint32: bit c set = colour channel c was clamped at 0 */
 #define GSR_REC_DEPTH 12    /* view-space z                                        */
 #define GSR_REC_RECT_MIN 13 /* uint32: tile rect min, x | y << 16                  */
 #define GSR_REC_RECT_MAX 14 /* uint32: tile rect max (exclusive), x | y << 16      */
@@ -99,31 +98,9 @@ const char* gsr_last_error(void);
  * gsr_bin_lists.  totals has gsr_totals_words(P) words (the rest is the call's
  * scratch) and is 16-byte aligned.
  *
- * The stage is two kernels, available separately so that a host can overlap
- * them: gsr_preprocess_geometry produces everything except record words 8-11
- * and is all the binning waits for; gsr_preprocess_color (SH -> RGB: 4/5 of the
- * stage's input bytes) is only needed by gsr_blend_fwd and may run on another
- * stream beside the depth sort.  gsr_preprocess_fwd runs both on one stream.
- * `raw` != 0: scales, rotations, opacities are the model's RAW parameters and
- * exp / normalize / sigmoid are applied in the kernel (see the raw variants).
  * visible (P) uint8, optional (may be NULL): radii > 0, the `visibility_filter`
  * render() returns (gaussian_renderer/__init__.py:99). */
 size_t gsr_totals_words(int P);
-int gsr_preprocess_geometry(int P, int raw, const float* means3D, const float* scales,
-                            float scale_modifier, const float* rotations, const float* opacities,
-                            const float* cov3D_precomp, const float* viewmatrix,
-                            const float* projmatrix, int W, int H, float tanfovx, float tanfovy,
-                            uint32_t* records, int32_t* radii, uint32_t* tiles_touched,
-                            uint32_t* depth_keys, uint32_t* rects, uint64_t* sort_vals,
-                            uint32_t* totals, uint8_t* visible, void* stream);
-/* shs_rest / n_rest: NULL / 0, or the model's _features_rest (P,n_rest,3) with shs =
- * _features_dc (P,1,3) and M = 1 + n_rest (scene/gaussian_model.py:108-111).
- * max_blocks > 0 caps the number of workgroups (the kernel strides over the Gaussians), for a
- * host that runs it beside the binning and wants it to leave wave slots free; 0 = no cap. */
-int gsr_preprocess_color(int P, int D, int M, const float* means3D, const float* shs,
-                         const float* shs_rest, int n_rest, const float* colors_precomp,
-                         const float* campos, const int32_t* radii, uint32_t* records,
-                         int max_blocks, void* stream);
 int gsr_preprocess_fwd(int P, int D, int M, const float* means3D, const float* scales,
                        float scale_modifier, const float* rotations, const float* opacities,
                        const float* shs, const float* colors_precomp, const float* cov3D_precomp,
@@ -131,7 +108,7 @@ int gsr_preprocess_fwd(int P, int D, int M, const float* means3D, const float* s
                        int W, int H, float tanfovx, float tanfovy, int prefiltered,
                        uint32_t* records, int32_t* radii, uint32_t* tiles_touched,
                        uint32_t* depth_keys, uint32_t* rects, uint64_t* sort_vals,
-                       uint32_t* totals, void* stream);
+                       uint32_t* totals, uint8_t* visible, void* stream);
 
 /* GaussianRasterizer.markVisible of the module (never called by the
  * reference's Python): present[i] = view-space z > 0.2. */
@@ -228,7 +205,8 @@ int gsr_preprocess_fwd_raw(int P, int D, int n_rest, const float* xyz, const flo
                            const float* viewmatrix, const float* projmatrix, const float* campos,
                            int W, int H, float tanfovx, float tanfovy, uint32_t* records,
                            int32_t* radii, uint32_t* tiles_touched, uint32_t* depth_keys,
-                           uint32_t* rects, uint64_t* sort_vals, uint32_t* totals, void* stream);
+                           uint32_t* rects, uint64_t* sort_vals, uint32_t* totals, uint8_t* visible,
+                           void* stream);
 int gsr_preprocess_bwd_raw(int P, int D, int n_rest, const float* xyz, const float* scaling_raw,
                            float scale_modifier, const float* rotation_raw, const float* opacity_raw,
                            const float* features_dc, const float* features_rest,

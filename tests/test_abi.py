@@ -21,7 +21,7 @@ def declared_symbols():
 
 def test_header_declares_the_expected_entry_points():
     syms = declared_symbols()
-    for s in ("gsr_version", "gsr_last_error", "gsr_preprocess_fwd", "gsr_mark_visible", "gsr_preprocess_geometry", "gsr_preprocess_color", "gsr_totals_words",
+    for s in ("gsr_version", "gsr_last_error", "gsr_preprocess_fwd", "gsr_mark_visible", "gsr_totals_words",
               "gsr_bin_sort_bytes", "gsr_bin_sort", "gsr_bin_lists_bytes", "gsr_bin_lists", "gsr_blend_fwd", "gsr_blend_bwd",
               "gsr_preprocess_bwd"):
         assert s in syms

@@ -45,62 +45,3 @@ def test_fused_activations_match_pytorch_activations(P, W, H, deg, max_deg):
     err = float((vs_a - vs_b).abs().max()) / (float(vs_a.abs().max()) + 1e-20)
     assert err < 2e-3
     assert float(vs_b[:, 2].abs().max()) == 0.0
-
-
-def test_single_stream_entry_points_match_the_split_ones():
-    """gsr_preprocess_fwd / gsr_preprocess_fwd_raw (geometry + colour on one stream, for hosts that do
-    not overlap them) write the same records, keys and list sizes as the module's two-stream path."""
-    import ctypes as C
-    import math
-    import diff_gaussian_rasterization as dgr
-    from gsplat_host.model import GaussianParams
-    cloud, cam, bg, _ = make_scene(7_000, 200, 136, sh_degree=3, seed=8, bg=(0.0, 0.0, 0.0))
-    cam.to("cuda")
-    model = GaussianParams(cloud, device="cuda")
-    s = dgr.GaussianRasterizationSettings(
-        image_height=136, image_width=200, tanfovx=math.tan(cam.FoVx * 0.5), tanfovy=math.tan(cam.FoVy * 0.5),
-        bg=bg.cuda(), scale_modifier=1.0, viewmatrix=cam.world_view_transform, projmatrix=cam.full_proj_transform,
-        sh_degree=3, campos=cam.camera_center, prefiltered=False, debug=False)
-    lib, ptr = dgr._lib, dgr._ptr
-    vp, ci, cf = C.c_void_p, C.c_int, C.c_float
-    lib.gsr_preprocess_fwd.argtypes = [ci, ci, ci, vp, vp, cf, vp, vp, vp, vp, vp, vp, vp, vp, ci, ci, cf, cf, ci,
-                                       vp, vp, vp, vp, vp, vp, vp, vp]
-    P = 7000
-    stream = dgr._stream()
-
-    def buffers():
-        i32 = dict(dtype=torch.int32, device="cuda")
-        return dict(records=torch.zeros((P, 16), **i32), radii=torch.zeros((P,), **i32), tiles=torch.zeros((P,), **i32),
-                    keys=torch.zeros((P,), **i32), rects=torch.zeros((P, 2), **i32),
-                    vals=torch.zeros((P,), dtype=torch.int64, device="cuda"),
-                    totals=torch.zeros((lib.gsr_totals_words(P),), **i32))
-
-    with torch.no_grad():
-        xyz, op, sc, ro, sh = model.get_xyz, model.get_opacity, model.get_scaling, model.get_rotation, model.get_features
-        st = dgr.rasterize_forward(s, xyz, op, shs=sh, scales=sc, rotations=ro)
-        b = buffers()
-        rc = lib.gsr_preprocess_fwd(P, 3, 16, ptr(xyz), ptr(sc), 1.0, ptr(ro), ptr(op), ptr(sh.contiguous()), None, None,
-                                    ptr(st.view), ptr(st.proj), ptr(st.campos), 200, 136, float(s.tanfovx),
-                                    float(s.tanfovy), 0, ptr(b["records"]), ptr(b["radii"]), ptr(b["tiles"]),
-                                    ptr(b["keys"]), ptr(b["rects"]), ptr(b["vals"]), ptr(b["totals"]), stream)
-        assert rc == 0, lib.gsr_last_error()
-        torch.cuda.synchronize()
-        vis = st.radii > 0
-        assert torch.equal(b["radii"], st.radii) and torch.equal(b["keys"], st.depth_keys)
-        assert torch.equal(b["records"][vis], st.records[vis]) and torch.equal(b["rects"], st.rect_words)
-        assert b["totals"][:4].tolist() == [st.num_rendered, b["totals"][1].item(), b["totals"][2].item(), st.num_visible]
-
-        raw = dict(features_dc=model._features_dc, features_rest=model._features_rest, scaling=model._scaling,
-                   rotation=model._rotation, opacity=model._opacity)
-        st2 = dgr.rasterize_forward(s, xyz, None, raw=raw)
-        b = buffers()
-        rc = lib.gsr_preprocess_fwd_raw(P, 3, 15, ptr(xyz), ptr(model._scaling), 1.0, ptr(model._rotation),
-                                        ptr(model._opacity), ptr(model._features_dc), ptr(model._features_rest),
-                                        ptr(st.view), ptr(st.proj), ptr(st.campos), 200, 136, float(s.tanfovx),
-                                        float(s.tanfovy), ptr(b["records"]), ptr(b["radii"]), ptr(b["tiles"]),
-                                        ptr(b["keys"]), ptr(b["rects"]), ptr(b["vals"]), ptr(b["totals"]), stream)
-        assert rc == 0, lib.gsr_last_error()
-        torch.cuda.synchronize()
-        vis = st2.radii > 0
-        assert torch.equal(b["radii"], st2.radii) and torch.equal(b["records"][vis], st2.records[vis])
-        assert int(b["totals"][0]) == st2.num_rendered and int(b["totals"][3]) == st2.num_visible
