@@ -48,6 +48,9 @@ WORKLOADS = {
 }
 
 
+DOMINANT_STAGE = "blend_bwd"      # the longest kernel of the step on every workload here
+
+
 def algorithmic_bytes(P, N, W, H, M=16):
     """Per-launch algorithmic HBM bytes of each stage (minimum traffic with
     perfect on-chip reuse): B_in = 44 + 12*M bytes of attributes per Gaussian,
@@ -134,7 +137,11 @@ def main():
     from gsplat_host.optim import GaussianAdam, all_reduce_gradients
     opt = GaussianAdam.for_model(model)
 
-    timer = dgr.StageTimer()
+    # Inside the timed steps only the dominant kernel is bracketed by events (every bracket costs
+    # the step a few microseconds of device idle time: all eight stages together ~0.09 ms of a
+    # 1.06 ms step); the per-stage table comes from a second, untimed pass.
+    timer = dgr.StageTimer(only=(DOMINANT_STAGE,))
+    all_stages = dgr.StageTimer()
     fwd_events = []
 
     def step(timed: bool):
@@ -173,6 +180,10 @@ def main():
         out = step(True)
     barrier()
     elapsed = time.perf_counter() - t0
+    dgr.set_stage_timer(all_stages)
+    for _ in range(args.steps):
+        step(False)
+    barrier()
     dgr.set_stage_timer(None)
 
     if use_dist:
@@ -201,11 +212,14 @@ def main():
     n_params = sum(p.numel() for p in params)
 
     if rank == 0:
-        stage_ms = timer.mean_ms()
+        stage_ms = all_stages.mean_ms()
+        stage_ms.update(timer.mean_ms())          # the dominant kernel: as measured inside the timed steps
         N = int((out["radii"] > 0).sum().item())
         st_N = _instances(dgr, cam, model, bg)
         alg = algorithmic_bytes(P, st_N, W, H)
         dominant = max(alg, key=lambda k: stage_ms.get(k, 0.0))
+        if dominant != DOMINANT_STAGE:
+            print(f"warning: {dominant} outlasts {DOMINANT_STAGE}; its time comes from the untimed pass", file=sys.stderr)
         achieved = alg[dominant] / (stage_ms[dominant] * 1e-3) / 1e9
         kernels = {k: {"ms": round(stage_ms[k], 4), "algorithmic_GB": round(alg[k] / 1e9, 4) if k in alg else None,
                        "GBps": round(alg[k] / (stage_ms[k] * 1e-3) / 1e9, 1) if k in alg else None}

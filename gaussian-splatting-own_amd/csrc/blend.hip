@@ -33,16 +33,46 @@ __device__ __forceinline__ Pixel my_pixel(int W, int H) {
   return p;
 }
 
-// 4-bit mask: which 8x8 quadrants of the tile can see a splat centred at
-// (sx,sy) whose alpha >= 1/255 region spans +-hx, +-hy (negative = never).
-__device__ __forceinline__ unsigned quadrant_mask(float sx, float sy, float hx, float hy, float tx0, float ty0) {
+// Does the ellipse A dx^2 + 2B dx dy + C dy^2 <= tau around the splat centre reach the box
+// [a0,a1] x [b0,b1] (offsets from the centre)?  The form is convex with its minimum at the centre,
+// so over a box that does not hold the centre it is smallest on one of the two edges facing the
+// centre: on dx = ax at dy = -B ax / C, on dy = by at dx = -B by / A, each clamped to the edge.
+// nBA = -B/A, nBC = -B/C.  Written so that a NaN anywhere answers "yes".
+__device__ __forceinline__ bool ellipse_reaches_box(float A, float B, float C, float nBA, float nBC, float tau,
+                                                    float a0, float a1, float b0, float b1) {
+  const float ax = fminf(fmaxf(0.0f, a0), a1), by = fminf(fmaxf(0.0f, b0), b1);
+  const float dy1 = fminf(fmaxf(nBC * ax, b0), b1);
+  const float dx2 = fminf(fmaxf(nBA * by, a0), a1);
+  const float f1 = A * ax * ax + 2.0f * B * ax * dy1 + C * dy1 * dy1;
+  const float f2 = A * dx2 * dx2 + 2.0f * B * dx2 * by + C * by * by;
+  return !(fminf(f1, f2) > tau);
+}
+
+// 4-bit mask: which 8x8 quadrants of the tile can see a splat centred at (sx,sy) with conic
+// (A,B,C) and opacity o.  A pixel blends the splat only where o exp(-q/2) >= 1/255, i.e. inside
+// the ellipse q <= 2 ln(255 o); (hx,hy) are the half extents of that ellipse's bounding box
+// (negative = never).  Box test first, then the ellipse itself against each quadrant's pixel
+// centres; tau is widened a little so that rounding can never make the test exclusive.
+__device__ __forceinline__ unsigned quadrant_mask(float sx, float sy, float hx, float hy, float A, float B, float C,
+                                                  float o, float tx0, float ty0) {
   if (hx < 0.0f) return 0u;
   const float lx = sx - hx, rx = sx + hx, ly = sy - hy, ry = sy + hy;
   const bool xl = (rx >= tx0) && (lx <= tx0 + 7.0f);
   const bool xr = (rx >= tx0 + 8.0f) && (lx <= tx0 + 15.0f);
   const bool yt = (ry >= ty0) && (ly <= ty0 + 7.0f);
   const bool yb = (ry >= ty0 + 8.0f) && (ly <= ty0 + 15.0f);
-  return (unsigned)(xl && yt) | ((unsigned)(xr && yt) << 1) | ((unsigned)(xl && yb) << 2) | ((unsigned)(xr && yb) << 3);
+  unsigned m = (unsigned)(xl && yt) | ((unsigned)(xr && yt) << 1) | ((unsigned)(xl && yb) << 2) | ((unsigned)(xr && yb) << 3);
+  if (m == 0u) return 0u;
+  const float tau = 2.0f * __logf(255.0f * o) * 1.001f + 0.01f;
+  const float nBA = -B / A, nBC = -B / C;
+  const float ax0 = tx0 - sx, ay0 = ty0 - sy;
+  unsigned e = 0u;
+#pragma unroll
+  for (int q = 0; q < 4; q++) {
+    const float a0 = ax0 + (float)((q & 1) * 8), b0 = ay0 + (float)((q >> 1) * 8);
+    e |= (unsigned)ellipse_reaches_box(A, B, C, nBA, nBC, tau, a0, a0 + 7.0f, b0, b0 + 7.0f) << q;
+  }
+  return m & e;
 }
 
 __device__ __forceinline__ unsigned long long lds_mask(const unsigned long long* m) {
@@ -118,7 +148,8 @@ __global__ void __launch_bounds__(256) blend_fwd_kernel(int W, int H, const uint
       const uint4* rec = records + (size_t)g * 4;
       const uint4 r0 = rec[0], r1 = rec[1], r2 = rec[2];
       const float sx = __uint_as_float(r0.x), sy = __uint_as_float(r0.y);
-      qm = quadrant_mask(sx, sy, __uint_as_float(r0.z), __uint_as_float(r0.w), tx0, ty0);
+      qm = quadrant_mask(sx, sy, __uint_as_float(r0.z), __uint_as_float(r0.w), __uint_as_float(r1.x),
+                         __uint_as_float(r1.y), __uint_as_float(r1.z), __uint_as_float(r1.w), tx0, ty0);
       const Staged sp = stage_record(r0, r1, r2);
       s_geo[threadIdx.x] = sp.geo;
       s_col[threadIdx.x] = sp.col;
@@ -252,7 +283,8 @@ __global__ void __launch_bounds__(256) blend_bwd_kernel(int W, int H, const uint
       const uint4* rec = records + (size_t)g * 4;
       const uint4 r0 = rec[0], r1 = rec[1], r2 = rec[2];
       const float sx = __uint_as_float(r0.x), sy = __uint_as_float(r0.y);
-      qm = quadrant_mask(sx, sy, __uint_as_float(r0.z), __uint_as_float(r0.w), tx0, ty0);
+      qm = quadrant_mask(sx, sy, __uint_as_float(r0.z), __uint_as_float(r0.w), __uint_as_float(r1.x),
+                         __uint_as_float(r1.y), __uint_as_float(r1.z), __uint_as_float(r1.w), tx0, ty0);
       const Staged sp = stage_record(r0, r1, r2);
       s_geo[threadIdx.x] = sp.geo;
       s_col[threadIdx.x] = sp.col;

@@ -74,10 +74,13 @@ _lib = _load()
 class StageTimer:
     """Optional per-stage device timing: while one is installed with
     ``set_stage_timer``, every C-ABI call is bracketed by a pair of events on
-    the current stream (the stream the kernels run on)."""
+    the current stream (the stream the kernels run on).  ``only`` restricts the brackets to the
+    named stages: each bracket costs a few microseconds of device idle time, so a timed region
+    that is itself being measured should carry as few as it can."""
 
-    def __init__(self):
+    def __init__(self, only=None):
         self.events = {}
+        self.only = None if only is None else frozenset(only)
 
     def bracket(self, name):
         e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
@@ -102,7 +105,7 @@ def set_stage_timer(timer: Optional[StageTimer]) -> None:
 
 
 def _run(what: str, fn, *args) -> None:
-    if _timer is not None:
+    if _timer is not None and (_timer.only is None or what in _timer.only):
         e0, e1 = _timer.bracket(what)
         e0.record()
         rc = fn(*args)
