@@ -265,7 +265,7 @@ __global__ void __launch_bounds__(256) blend_bwd_kernel(int W, int H, const uint
   for (int o = 32; o > 0; o >>= 1) wl = max(wl, __shfl_xor(wl, o));
   if (lane == 0) s_last[wave] = wl;
   __syncthreads();
-  const int wave_last = wl;
+  const int wave_last = __builtin_amdgcn_readfirstlane(wl);
   const int tile_last = max(max(s_last[0], s_last[1]), max(s_last[2], s_last[3]));
   if (tile_last == 0 || total == 0) return;
 
@@ -301,6 +301,10 @@ __global__ void __launch_bounds__(256) blend_bwd_kernel(int W, int H, const uint
     if (b * kBatch >= wave_last) continue;   // nothing this deep for this quadrant
     for (int sw = 3; sw >= 0; sw--) {
       unsigned long long m = lds_mask(&s_mask[px.quad][sw]);
+      // positions at or beyond the deepest one any pixel of this quadrant used contribute nothing
+      const int room = wave_last - (b * kBatch + sw * 64);
+      if (room <= 0) continue;
+      if (room < 64) m &= (1ull << room) - 1ull;
       while (m) {
         const int bit = 63 - __clzll((long long)m);
         m &= ~(1ull << bit);

@@ -44,11 +44,13 @@ def median_scale(P: int, extent: float = 2.6) -> float:
 
 def make_cloud(P: int, sh_degree: int = 3, seed: int = 0, skew_fraction: float = 0.0,
                opacity_const: float | None = None, scale_mult: float = 1.0,
-               coeffs: int | None = None) -> Cloud:
+               coeffs: int | None = None, anisotropy: float = 1.0) -> Cloud:
     """P random Gaussians.  ``skew_fraction`` of them are drawn N(0, 0.1^2)
     around the origin instead (hot tiles).  ``opacity_const`` replaces the
     sigmoid(N(0,2^2)) opacities by one value (0.1 = the reference's
-    initialisation, scene/gaussian_model.py:139: no early termination)."""
+    initialisation, scene/gaussian_model.py:139: no early termination).
+    ``anisotropy`` a stretches the first axis by a and shrinks the other two by a (needles at
+    random orientations for a >> 1); applied after all random draws."""
     g = torch.Generator().manual_seed(seed)
     xyz = (torch.rand(P, 3, generator=g) * 2.0 - 1.0) * 1.3
     if skew_fraction > 0.0:
@@ -56,6 +58,8 @@ def make_cloud(P: int, sh_degree: int = 3, seed: int = 0, skew_fraction: float =
         xyz[:n] = torch.randn(n, 3, generator=g) * 0.1
     s0 = median_scale(P) * scale_mult
     scaling = torch.exp(math.log(s0) + 0.5 * torch.randn(P, 3, generator=g))
+    if anisotropy != 1.0:
+        scaling = scaling * torch.tensor([anisotropy, 1.0 / anisotropy, 1.0 / anisotropy])
     q = torch.randn(P, 4, generator=g)
     rotation = q / q.norm(dim=1, keepdim=True)
     if opacity_const is None:

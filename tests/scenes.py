@@ -13,9 +13,9 @@ from gsplat_host.synthetic import make_cloud
 
 
 def make_scene(P, W, H, sh_degree=3, seed=0, angle=0.0, scale_mult=1.0, bg=(0.0, 0.0, 0.0),
-               skew_fraction=0.0, opacity_const=None, coeffs=16, scale_modifier=1.0, distance=4.0):
+               skew_fraction=0.0, opacity_const=None, coeffs=16, scale_modifier=1.0, distance=4.0, anisotropy=1.0):
     cloud = make_cloud(P, sh_degree=sh_degree, seed=seed, skew_fraction=skew_fraction,
-                       opacity_const=opacity_const, scale_mult=scale_mult, coeffs=coeffs)
+                       opacity_const=opacity_const, scale_mult=scale_mult, coeffs=coeffs, anisotropy=anisotropy)
     cam = orbit_camera(W, H, angle_deg=angle, distance=distance)
     return cloud, cam, torch.tensor(bg, dtype=torch.float32), scale_modifier
 

@@ -43,6 +43,8 @@ CASES = {
     "deg1_close_camera": (6_000, 320, 320, 1, 16, (0.0, 0.0, 0.0), 1.0, dict(distance=1.6, scale_mult=2.0)),
     "skewed_hot_tiles": (30_000, 320, 192, 3, 16, (0.1, 0.1, 0.1), 1.0, dict(skew_fraction=0.5)),
     "low_opacity_no_termination": (8_000, 256, 256, 3, 16, (0.0, 0.0, 0.0), 1.0, dict(opacity_const=0.1)),
+    # thin, long splats at random angles: bounding boxes far larger than the ellipses the blend culls with
+    "needles": (1_500, 320, 240, 1, 4, (0.0, 0.0, 0.0), 1.0, dict(anisotropy=6.0, scale_mult=0.25)),
     # binning extremes: rectangles that span every supercell, lists far longer than a partition piece,
     # a grid of 135 supercells with partial ones at both edges, a one-tile image
     "screen_filling_splats_1080p": (400, 1920, 1080, 0, 1, (0.0, 0.0, 0.0), 1.0, dict(scale_mult=6.0)),
@@ -50,6 +52,15 @@ CASES = {
     "one_hot_tile": (12_000, 96, 64, 0, 1, (0.0, 0.0, 0.0), 1.0, dict(skew_fraction=1.0, distance=30.0)),
     "single_tile_image": (500, 16, 16, 0, 1, (0.3, 0.3, 0.3), 1.0, {}),
 }
+
+
+# faint, overlapping needles leave more pixels within rounding distance of a 1/255 decision, and
+# their conics are ill-conditioned: the exponent is a small difference of large terms, so the two
+# roundings of it (C float expression order there, fused multiply-adds in the log2 domain here)
+# differ by up to ~1e-4 relative in alpha
+MAX_BORDERLINE = {"needles": 1e-2}
+LOOSE = {"needles": 30.0}      # factor on the blend tolerances
+LOOSE_GEOMETRY = {"needles": 300.0}   # ... and on gradients that pass through the inverse of a near-singular 2x2
 
 
 def _run_case(oracle32, name):
@@ -97,12 +108,13 @@ def test_forward_stages(oracle32, name):
     safe = fw["margin"] >= MARGIN_SAFE
     frac_unsafe = 1.0 - safe.mean()
     print(name, "threshold-borderline pixels: %.4f%%" % (100 * frac_unsafe), flush=True)
-    assert frac_unsafe < 5e-3
+    assert frac_unsafe < MAX_BORDERLINE.get(name, 5e-3)
     diff = np.abs(color - fw["color"])
-    assert diff[:, safe].max() <= PIX_TOL, diff[:, safe].max()
+    loose = LOOSE.get(name, 1.0)
+    assert diff[:, safe].max() <= PIX_TOL * loose, diff[:, safe].max()
     assert diff.max() < 2e-2                       # a flipped decision moves a pixel by one contribution at most
     assert np.array_equal(st.n_contrib.cpu().numpy().view(np.uint32)[safe], fw["n_contrib"][safe])
-    np.testing.assert_allclose(st.final_T.cpu().numpy()[safe], fw["final_T"][safe], rtol=2e-5, atol=1e-7)
+    np.testing.assert_allclose(st.final_T.cpu().numpy()[safe], fw["final_T"][safe], rtol=2e-5 * loose, atol=1e-7)
 
 
 def _rel_err(got, ref):
@@ -111,7 +123,7 @@ def _rel_err(got, ref):
 
 
 @pytest.mark.parametrize("name", ["c1_10k_256_deg0", "ragged_5k_333x200_deg3", "deg1_close_camera",
-                                  "skewed_hot_tiles", "low_opacity_no_termination"])
+                                  "skewed_hot_tiles", "low_opacity_no_termination", "needles"])
 def test_backward(oracle32, name):
     import diff_gaussian_rasterization as dgr
     cloud, cam, bg, mod, s_cpu, s_gpu, cn, ref, st = _run_case(oracle32, name)
@@ -136,12 +148,12 @@ def test_backward(oracle32, name):
                           ("opacity", ds["opacity"], bb["dL_dopacity"]), ("color", ds["color"], bb["dL_dcolor"])]:
         e = _rel_err(got, want)
         print(name, "blend_bwd", nm, "rel err %.2e" % e, flush=True)
-        assert e < 2e-5, (nm, e)
+        assert e < 2e-5 * LOOSE.get(name, 1.0), (nm, e)
     for nm in ("means3D", "means2D", "shs", "opacities", "scales", "rotations"):
         got, want = g[nm].cpu().numpy(), g_ref[nm]
         e = _rel_err(got, want.reshape(got.shape))
         print(name, "grad", nm, "rel err %.2e" % e, flush=True)
-        assert e < 3e-5, (nm, e)
+        assert e < 3e-5 * (LOOSE_GEOMETRY if nm in ("scales", "rotations") else LOOSE).get(name, 1.0), (nm, e)
         assert np.isfinite(got).all()
 
 
