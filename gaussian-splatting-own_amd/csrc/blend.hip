@@ -90,21 +90,22 @@ __device__ __forceinline__ float gauss_exponent(float la, float lb, float lc, fl
   return fmaf(lb * dx, dy, fmaf(la * dx, dx, (lc * dy) * dy));
 }
 
-// What a staging thread publishes about one splat.
-struct Staged {
-  float4 geo;   // x, y, la, lb
-  float4 col;   // lc, opacity, r, g
+// What a staging thread publishes about one splat: one 48-byte LDS slot, so that the waves reading it
+// back (every lane the same slot: broadcast reads) need a single address register per splat.
+struct __align__(16) Staged {
+  float4 geo;      // x, y, la, lb
+  float4 col;      // lc, opacity, r, g
   float blue;
+  uint32_t id;     // Gaussian index (backward only)
+  float pad[2];
 };
 
-__device__ __forceinline__ Staged stage_record(const uint4 r0, const uint4 r1, const uint4 r2) {
-  Staged s;
-  s.geo = make_float4(__uint_as_float(r0.x), __uint_as_float(r0.y), -0.5f * kLog2e * __uint_as_float(r1.x),
-                      -kLog2e * __uint_as_float(r1.y));
-  s.col = make_float4(-0.5f * kLog2e * __uint_as_float(r1.z), __uint_as_float(r1.w), __uint_as_float(r2.x),
-                      __uint_as_float(r2.y));
-  s.blue = __uint_as_float(r2.z);
-  return s;
+__device__ __forceinline__ void stage_record(Staged* slot, const uint4 r0, const uint4 r1, const uint4 r2, uint32_t id) {
+  slot->geo = make_float4(__uint_as_float(r0.x), __uint_as_float(r0.y), -0.5f * kLog2e * __uint_as_float(r1.x),
+                          -kLog2e * __uint_as_float(r1.y));
+  slot->col = make_float4(-0.5f * kLog2e * __uint_as_float(r1.z), __uint_as_float(r1.w), __uint_as_float(r2.x),
+                          __uint_as_float(r2.y));
+  *reinterpret_cast<float2*>(&slot->blue) = make_float2(__uint_as_float(r2.z), __uint_as_float(id));
 }
 
 // ---------------------------------------------------------------------------
@@ -115,9 +116,7 @@ __global__ void __launch_bounds__(256) blend_fwd_kernel(int W, int H, const uint
                                                         const uint4* __restrict__ records,
                                                         const float* __restrict__ bg, float* __restrict__ out_color,
                                                         float* __restrict__ final_T, uint32_t* __restrict__ n_contrib) {
-  __shared__ float4 s_geo[kBatch];   // x, y, -A/2*log2e, -B*log2e
-  __shared__ float4 s_col[kBatch];   // -C/2*log2e, opacity, r, g
-  __shared__ float s_blue[kBatch];
+  __shared__ Staged s_splat[kBatch];
   __shared__ unsigned long long s_mask[4][4];  // [quadrant][staging wave]
 
   const Pixel px = my_pixel(W, H);
@@ -150,10 +149,7 @@ __global__ void __launch_bounds__(256) blend_fwd_kernel(int W, int H, const uint
       const float sx = __uint_as_float(r0.x), sy = __uint_as_float(r0.y);
       qm = quadrant_mask(sx, sy, __uint_as_float(r0.z), __uint_as_float(r0.w), __uint_as_float(r1.x),
                          __uint_as_float(r1.y), __uint_as_float(r1.z), __uint_as_float(r1.w), tx0, ty0);
-      const Staged sp = stage_record(r0, r1, r2);
-      s_geo[threadIdx.x] = sp.geo;
-      s_col[threadIdx.x] = sp.col;
-      s_blue[threadIdx.x] = sp.blue;
+      stage_record(&s_splat[threadIdx.x], r0, r1, r2, g);
     }
 #pragma unroll
     for (int q = 0; q < 4; q++) {
@@ -169,9 +165,10 @@ __global__ void __launch_bounds__(256) blend_fwd_kernel(int W, int H, const uint
           const int bit = __ffsll((long long)m) - 1;
           m &= ~(1ull << bit);
           const int j = sw * 64 + bit;
-          const float4 ga = s_geo[j];
-          const float4 co = s_col[j];
-          const float blue = s_blue[j];
+          const Staged* sp = &s_splat[j];
+          const float4 ga = sp->geo;
+          const float4 co = sp->col;
+          const float blue = sp->blue;
           const float dx = ga.x - pxf, dy = ga.y - pyf;
           const float p = gauss_exponent(ga.z, ga.w, co.x, dx, dy);
           // alpha = min(.99, oG) is kept iff the exponent is <= 0 and alpha >= 1/255, i.e. oG >= 1/255
@@ -179,7 +176,7 @@ __global__ void __launch_bounds__(256) blend_fwd_kernel(int W, int H, const uint
           const bool keep = (p <= 0.0f) & (oG >= GSR_ALPHA_MIN) & (live != 0.0f);
           if (__ballot(keep) == 0ull) continue;               // no pixel of the quadrant takes this splat
           oG = keep ? oG : 0.0f;
-          const float alpha = fminf(GSR_ALPHA_MAX, oG);
+          const float alpha = __builtin_amdgcn_fmed3f(oG, 0.0f, GSR_ALPHA_MAX);   // min(.99, oG) for oG >= 0
           const float test_T = T * (1.0f - alpha);            // alpha == 0: exactly T
           const bool stop = test_T < GSR_T_STOP;               // implies alpha > 0 (T >= T_STOP while live)
           const float w = stop ? 0.0f : alpha * T;
@@ -188,7 +185,7 @@ __global__ void __launch_bounds__(256) blend_fwd_kernel(int W, int H, const uint
           C0 = fmaf(co.z, w, C0);
           C1 = fmaf(co.w, w, C1);
           C2 = fmaf(blue, w, C2);
-          last = w > 0.0f ? (uint32_t)(b * kBatch + j + 1) : last;
+          last = (keep & !stop) ? (uint32_t)(b * kBatch + j + 1) : last;   // exactly the pixels with w > 0
         }
         if (__ballot(live != 0.0f) == 0ull) break;
       }
@@ -238,10 +235,7 @@ __global__ void __launch_bounds__(256) blend_bwd_kernel(int W, int H, const uint
                                                         const uint32_t* __restrict__ n_contrib,
                                                         const float* __restrict__ dL_dpix,
                                                         float* __restrict__ dL_dsplat) {
-  __shared__ float4 s_geo[kBatch];   // x, y, -A/2*log2e, -B*log2e
-  __shared__ float4 s_col[kBatch];   // -C/2*log2e, opacity, r, g
-  __shared__ float s_blue[kBatch];
-  __shared__ uint32_t s_id[kBatch];
+  __shared__ Staged s_splat[kBatch];
   __shared__ unsigned long long s_mask[4][4];
   __shared__ int s_last[4];
   __shared__ __align__(16) float s_red[4][8 * kRedStride];   // per wave: 8 rows of 64 lane values
@@ -285,11 +279,7 @@ __global__ void __launch_bounds__(256) blend_bwd_kernel(int W, int H, const uint
       const float sx = __uint_as_float(r0.x), sy = __uint_as_float(r0.y);
       qm = quadrant_mask(sx, sy, __uint_as_float(r0.z), __uint_as_float(r0.w), __uint_as_float(r1.x),
                          __uint_as_float(r1.y), __uint_as_float(r1.z), __uint_as_float(r1.w), tx0, ty0);
-      const Staged sp = stage_record(r0, r1, r2);
-      s_geo[threadIdx.x] = sp.geo;
-      s_col[threadIdx.x] = sp.col;
-      s_blue[threadIdx.x] = sp.blue;
-      s_id[threadIdx.x] = g;
+      stage_record(&s_splat[threadIdx.x], r0, r1, r2, g);
     }
 #pragma unroll
     for (int q = 0; q < 4; q++) {
@@ -310,9 +300,10 @@ __global__ void __launch_bounds__(256) blend_bwd_kernel(int W, int H, const uint
         m &= ~(1ull << bit);
         const int j = sw * 64 + bit;
         const int pos = b * kBatch + j;   // 0-based position in the tile list
-        const float4 ga = s_geo[j];
-        const float4 co = s_col[j];
-        const float blue = s_blue[j];
+        const Staged* sp = &s_splat[j];
+        const float4 ga = sp->geo;
+        const float4 co = sp->col;
+        const float blue = sp->blue;
         const float dx = ga.x - pxf, dy = ga.y - pyf;
         // same alpha and same keep / skip decision as the forward (min(.99, oG) >= 1/255 exactly when
         // oG >= 1/255), as straight-line code: a pixel that did not blend this splat gets oG = 0,
@@ -322,7 +313,7 @@ __global__ void __launch_bounds__(256) blend_bwd_kernel(int W, int H, const uint
         const bool hit = (p <= 0.0f) & (oG >= GSR_ALPHA_MIN) & (pos < last);
         if (__ballot(hit) == 0ull) continue;
         oG = hit ? oG : 0.0f;
-        const float alpha = fminf(GSR_ALPHA_MAX, oG);
+        const float alpha = __builtin_amdgcn_fmed3f(oG, 0.0f, GSR_ALPHA_MAX);   // min(.99, oG) for oG >= 0
 
         const float inv = __builtin_amdgcn_rcpf(1.0f - alpha);     // alpha == 0: exactly 1
         T = T * inv;                                               // transmittance in front of the splat
@@ -364,7 +355,7 @@ __global__ void __launch_bounds__(256) blend_bwd_kernel(int W, int H, const uint
         // wave-instruction on nine consecutive dwords of one 64-byte row = one atomic request
         const bool ninth = lane == 1;
         if ((lane & 7) == 0 || ninth)
-          atomicAdd(dL_dsplat + (size_t)s_id[j] * GSR_GRAD_WORDS + (ninth ? 8 : (lane >> 3)), ninth ? v8 : v);
+          atomicAdd(dL_dsplat + (size_t)sp->id * GSR_GRAD_WORDS + (ninth ? 8 : (lane >> 3)), ninth ? v8 : v);
       }
     }
   }

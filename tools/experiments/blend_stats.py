@@ -35,6 +35,6 @@ for wl in sys.argv[1:] or ["c3"]:
     tiles = ((W + 15) // 16) * ((H + 15) // 16)
     print(f"{wl}: tiles {tiles}")
     print(f"  fwd staged {v[3]} ({v[3] / tiles:.0f}/tile)  wave iterations {v[0]} ({v[0] / tiles / 4:.0f}/wave)  "
-          f"voted in {v[1]} ({100 * v[1] / max(v[0], 1):.1f}%)  lanes per voted-in {v[2] / max(v[1], 1):.1f}")
+          f"voted in {v[1]} ({100 * v[1] / max(v[0], 1):.1f}%)  lanes per voted-in {v[2] / max(v[1], 1):.1f} of 64")
     print(f"  bwd staged {v[7]} ({v[7] / tiles:.0f}/tile)  wave iterations {v[4]} ({v[4] / tiles / 4:.0f}/wave)  "
-          f"voted in {v[5]} ({100 * v[5] / max(v[4], 1):.1f}%)  lanes per voted-in {v[6] / max(v[5], 1):.1f}", flush=True)
+          f"voted in {v[5]} ({100 * v[5] / max(v[4], 1):.1f}%)  lanes per voted-in {v[6] / max(v[5], 1):.1f} of 64", flush=True)
