@@ -30,10 +30,8 @@
 // Gaussian's index packed with its tile rectangle (bit widths chosen per call
 // from P and the tile grid), and that word is what levels 1 and 2 read.
 //
-// The depth sort is a rocPRIM radix sort; the rest is written here.
+// The depth sort itself lives in depthsort.hip.
 #include <cstring>
-
-#include <rocprim/rocprim.hpp>
 
 #include "gsr_common.h"
 
@@ -455,19 +453,6 @@ __global__ void __launch_bounds__(kBlock) fill_tile_ids_kernel(const uint32_t* _
   for (uint32_t i = b + threadIdx.x; i < e; i += kBlock) tile_ids[i] = t;
 }
 
-// rocPRIM switches to a block sort + log2(P/block) merge passes below 2^20 items; for the
-// ~1M depth keys of a large scene four Onesweep radix passes move far fewer bytes.
-// (Three passes of 11 bits, which the Onesweep configuration allows, took 3x as long.)
-using DepthSortConfig =
-    rocprim::radix_sort_config<rocprim::default_config, rocprim::default_config, rocprim::default_config, (1u << 16)>;
-
-size_t depth_sort_temp_bytes(int P) {
-  size_t bytes = 0;
-  (void)rocprim::radix_sort_pairs<DepthSortConfig>(nullptr, bytes, (const uint32_t*)nullptr, (uint32_t*)nullptr,
-                                  (const u64*)nullptr, (u64*)nullptr, (size_t)P, 0, 32);
-  return bytes;
-}
-
 // Scratch layout of gsr_bin_lists, in 256-byte aligned pieces.
 struct ListsLayout {
   size_t counts1, list_start2, list_len2, piece_first2, desc2, entries1, counts2;
@@ -506,29 +491,17 @@ int gsr::launch_totals_final(int blocks, const uint32_t* partials, uint32_t* tot
   return gsr::check_launch("totals");
 }
 
-extern "C" size_t gsr_bin_sort_bytes(int P) {
-  if (P <= 0) return 256;
-  return gsr::align_up((size_t)P * 4, 256) + gsr::align_up(depth_sort_temp_bytes(P), 256) + 256;
-}
+extern "C" size_t gsr_bin_sort_bytes(int P) { return gsr::depth_sort_bytes(P); }
 
 extern "C" int gsr_bin_sort(int P, const uint32_t* depth_keys, const uint64_t* sort_vals, uint64_t* sorted_vals,
                             void* scratch, size_t scratch_bytes, void* stream) {
-  GSR_REQUIRE(P >= 0, "bin_sort: bad P");
+  GSR_REQUIRE(P >= 0 && P < (1 << 30), "bin_sort: bad P");
   if (P == 0) return GSR_OK;
   GSR_REQUIRE(depth_keys && sort_vals && sorted_vals && scratch, "bin_sort: null pointer");
   if (scratch_bytes < gsr_bin_sort_bytes(P) || ((uintptr_t)scratch & 255))
     return gsr::fail(GSR_E_SCRATCH, "bin_sort: scratch too small (%zu < %zu) or not 256-byte aligned", scratch_bytes,
                      gsr_bin_sort_bytes(P));
-  char* base = (char*)scratch;
-  const size_t keys_bytes = gsr::align_up((size_t)P * 4, 256);
-  uint32_t* keys_sorted = (uint32_t*)base;
-  void* temp = base + keys_bytes;
-  size_t temp_bytes = scratch_bytes - keys_bytes;
-  hipError_t e = rocprim::radix_sort_pairs<DepthSortConfig>(temp, temp_bytes, depth_keys, keys_sorted,
-                                           (const u64*)sort_vals, (u64*)sorted_vals, (size_t)P, 0, 32,
-                                           (hipStream_t)stream);
-  if (e != hipSuccess) return gsr::fail(GSR_E_LAUNCH, "bin_sort: depth sort: %s", hipGetErrorString(e));
-  return gsr::check_launch("bin_sort");
+  return gsr::depth_sort(P, depth_keys, sort_vals, sorted_vals, scratch, (hipStream_t)stream);
 }
 
 extern "C" size_t gsr_bin_lists_bytes(uint32_t V, uint32_t E1, uint32_t E2, int W, int H) {

@@ -1,0 +1,379 @@
+// Depth sort of the binning for gfx950: a stable least-significant-digit radix sort of
+// (32-bit depth key, 64-bit value) pairs, 8 bits per pass, each pass one kernel ("Onesweep":
+// the digit histograms of all four passes are taken up front, and within a pass a workgroup
+// learns how many equal digits sit in earlier workgroups through a chained look-back instead
+// of a separate count + scan launch).
+//
+// What the general-purpose library sort cannot know and this one uses:
+//  * culled Gaussians (key 0xFFFFFFFF) are dropped by the first pass, so the later passes move
+//    only the visible ones, and only the first `visible` entries of the output are defined
+//    (that is all the list builder reads);
+//  * after the last pass nobody needs the keys: it writes values only;
+//  * all per-pass state (look-back words, workgroup tickets, histograms) is cleared by ONE
+//    launch for the whole sort, and the bin scan runs inside the pass kernels:
+//    6 launches per sort instead of 15;
+//  * the look-back is two-level and windowed: a workgroup sums the counts of the (at most 15)
+//    earlier workgroups of its group of 16 with all loads in flight together, the last workgroup
+//    of a group publishes the group's count and later its inclusive prefix, and everybody looks
+//    back over groups the same way.  When all workgroups of a pass are resident at once (a 1M-key
+//    sort: 245 of them) nobody finishes early, so a one-level look-back degenerates into every
+//    workgroup walking over all its predecessors, one memory latency per step; here it is about
+//    three latencies whatever the position.
+//
+// Forward progress: a workgroup takes its number from an atomic ticket when it starts running,
+// so every workgroup it waits for is already running or done; the waits are bounded by a spin
+// limit anyway (on overrun the sort sets an error word and still terminates).
+#include "gsr_common.h"
+
+namespace {
+
+typedef unsigned long long u64;
+
+constexpr int kThreads = 1024;
+constexpr int kWaves = kThreads / 64;
+// keys per thread and pass: 4 keeps a 1M-key sort at one short workgroup per CU; 8 amortises the
+// per-workgroup latencies (ticket, look-back) once there are several rounds of workgroups anyway
+constexpr int kFewItems = 4, kManyItems = 8;
+constexpr uint32_t kManyFrom = 4500000u;
+constexpr uint32_t kCulled = 0xFFFFFFFFu;
+constexpr uint32_t kPartial = 1u << 30, kComplete = 2u << 30, kFlags = 3u << 30;
+constexpr int kGroup = 16;                 // workgroups per look-back group
+constexpr int kWindow = 16;                // predecessors inspected per look-back step
+constexpr uint32_t kSpinLimit = 1u << 22;  // look-back steps before giving up (never reached in a healthy run)
+
+// control words behind the 4 x 256 histogram bins
+enum { kCtlValid = 0, kCtlTicket = 1, kCtlError = 5, kCtlWords = 16 };
+constexpr int kHistWords = 4 * 256;
+
+__device__ __forceinline__ uint32_t wave_incl_scan(uint32_t v) {
+  const int lane = threadIdx.x & 63;
+#pragma unroll
+  for (int o = 1; o < 64; o <<= 1) {
+    const uint32_t n = __shfl_up(v, o);
+    if (lane >= o) v += n;
+  }
+  return v;
+}
+
+__global__ void __launch_bounds__(256) sort_clear_kernel(uint32_t* __restrict__ words, size_t n) {
+  for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (size_t)gridDim.x * 256) words[i] = 0u;
+}
+
+// Digit histograms of all four passes over the keys of visible Gaussians, and their number.
+__global__ void __launch_bounds__(kThreads) sort_histogram_kernel(const uint32_t* __restrict__ keys, uint32_t P,
+                                                                  uint32_t* __restrict__ hist,
+                                                                  uint32_t* __restrict__ ctl) {
+  __shared__ uint32_t s_h[kHistWords];
+  __shared__ uint32_t s_valid;
+  s_h[threadIdx.x] = 0u;
+  if (threadIdx.x == 0) s_valid = 0u;
+  __syncthreads();
+  uint32_t valid = 0;
+  for (size_t i0 = (size_t)blockIdx.x * kThreads; i0 < P; i0 += (size_t)gridDim.x * kThreads) {
+    const size_t i = i0 + threadIdx.x;
+    const uint32_t k = i < P ? keys[i] : kCulled;
+    const bool ok = k != kCulled;
+    valid += ok ? 1u : 0u;
+    // Depth keys are floats: their upper bytes take few distinct values, and 64 lanes adding to one
+    // LDS word serialise.  The first few distinct digits of a wave are counted with a ballot and
+    // added once; what is left (well spread digits) goes through per-lane atomics.
+#pragma unroll
+    for (int place = 0; place < 4; place++) {
+      const uint32_t d = (k >> (8 * place)) & 255u;
+      unsigned long long rest = __ballot(ok);
+#pragma unroll
+      for (int it = 0; it < 3; it++) {
+        if (rest == 0ull) break;
+        const int first = __ffsll((long long)rest) - 1;
+        const uint32_t dv = (uint32_t)__shfl((int)d, first);
+        const unsigned long long same = __ballot(ok && d == dv) & rest;
+        if ((int)(threadIdx.x & 63) == first) atomicAdd(&s_h[256 * place + dv], (uint32_t)__popcll(same));
+        rest &= ~same;
+      }
+      if ((rest >> (threadIdx.x & 63)) & 1ull) atomicAdd(&s_h[256 * place + d], 1u);
+    }
+  }
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) valid += __shfl_xor(valid, o);
+  if ((threadIdx.x & 63) == 0 && valid) atomicAdd(&s_valid, valid);
+  __syncthreads();
+  const uint32_t c = s_h[threadIdx.x];
+  if (c) atomicAdd(&hist[threadIdx.x], c);
+  if (threadIdx.x == 0 && s_valid) atomicAdd(&ctl[kCtlValid], s_valid);   // one word for everybody: once per workgroup
+}
+
+struct PassArgs {
+  const uint32_t* keys_in;
+  const u64* vals_in;
+  uint32_t* keys_out;     // unused by the last pass
+  u64* vals_out;
+  const uint32_t* hist;   // this pass's 256 bins
+  uint32_t* ctl;
+  uint32_t* states;       // [workgroup][256] look-back words of this pass
+  uint32_t* group_states; // [group][256]
+  uint32_t P;
+};
+
+// Sum of the counts published at states[q][t] for q = p, p-1, ..., stop, newest first, waiting
+// for words that are still empty and ending early at a word flagged complete (which already
+// holds everything before it).
+__device__ __forceinline__ uint32_t look_back(const uint32_t* states, int p, int stop, int t, uint32_t* error_word,
+                                              uint32_t error_bit) {
+  uint32_t sum = 0, spins = 0;
+  while (p >= stop) {
+    uint32_t st[kWindow];
+#pragma unroll
+    for (int j = 0; j < kWindow; j++)
+      st[j] = (p - j >= stop) ? __hip_atomic_load(states + (size_t)(p - j) * 256 + t, __ATOMIC_RELAXED,
+                                                  __HIP_MEMORY_SCOPE_AGENT)
+                              : kComplete;
+    bool done = false;
+    int used = 0;
+#pragma unroll
+    for (int j = 0; j < kWindow; j++) {
+      if (!done && used == j && (st[j] & kFlags) != 0u) {
+        sum += st[j] & ~kFlags;
+        used = j + 1;
+        done = (st[j] & kFlags) == kComplete;
+      }
+    }
+    if (done) break;
+    p -= used;
+    if (++spins > kSpinLimit) { atomicOr(error_word, error_bit); break; }
+  }
+  return sum;
+}
+
+// One radix pass.  PASS 0 reads all P keys and drops the culled ones; later passes read the
+// ctl[kCtlValid] survivors.  Items are owned wave-striped (item i of lane l of wave w is element
+// w*256 + i*64 + l of the workgroup's chunk), ranked within the wave by matching digits with
+// ballots, and brought into workgroup order through LDS so that the global writes are runs.
+#ifdef GSR_SORT_TIMING
+__device__ long long g_sort_times[4][512][8];
+#define STAMP(k) do { if (tid == 0 && wg < 512) g_sort_times[PASS][wg][k] = wall_clock64(); } while (0)
+#else
+#define STAMP(k) do {} while (0)
+#endif
+
+template <int PASS, int kItemsPerThread>
+__global__ void __launch_bounds__(kThreads) sort_pass_kernel(PassArgs a) {
+  constexpr int kItems = kThreads * kItemsPerThread;   // keys per workgroup and pass
+  __shared__ uint32_t s_count[kWaves][256];   // per-wave digit counts, later the wave's offset within its digit
+  __shared__ uint32_t s_total[256];           // the workgroup's digit counts
+  __shared__ uint32_t s_local[256];           // first local rank of each digit
+  __shared__ uint32_t s_dest[256];            // global position of local rank 0 of each digit, minus that rank
+  __shared__ uint32_t s_keys[kItems];
+  __shared__ u64 s_vals[kItems];
+  __shared__ uint32_t s_misc[16];
+  constexpr int kShift = 8 * PASS;
+  const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
+
+  if (tid == 0) s_misc[0] = atomicAdd(&a.ctl[kCtlTicket + PASS], 1u);
+  if (tid < 256) s_total[tid] = 0u;
+#pragma unroll
+  for (int k = 0; k < kWaves * 256 / kThreads; k++) (&s_count[0][0])[k * kThreads + tid] = 0u;
+  __syncthreads();
+  const uint32_t wg = s_misc[0];
+  STAMP(0);
+  const uint32_t n = PASS == 0 ? a.P : a.ctl[kCtlValid];
+  const uint32_t base = wg * (uint32_t)kItems;
+  if (base >= n) return;                       // the whole workgroup: nothing left for it
+
+  const uint32_t bin = tid < 256 ? a.hist[tid] : 0u;
+
+  uint32_t key[kItemsPerThread], digit[kItemsPerThread], rank[kItemsPerThread];
+  u64 val[kItemsPerThread];
+  bool valid[kItemsPerThread];
+#pragma unroll
+  for (int i = 0; i < kItemsPerThread; i++) {
+    const uint32_t idx = base + (uint32_t)(wave * (64 * kItemsPerThread) + i * 64 + lane);
+    valid[i] = idx < n;
+    key[i] = valid[i] ? a.keys_in[idx] : kCulled;
+    val[i] = valid[i] ? a.vals_in[idx] : 0ull;      // both loads in flight together
+  }
+#pragma unroll
+  for (int i = 0; i < kItemsPerThread; i++) {
+    if (PASS == 0) valid[i] = key[i] != kCulled;
+    digit[i] = (key[i] >> kShift) & 255u;
+  }
+
+  // The workgroup's digit counts first, so that the look-back words go out before the ranking and
+  // travel while it runs.  The most common digit of each wave is counted with a ballot (the upper
+  // bytes of depth keys take few values, and 64 lanes adding to one LDS word serialise).
+#pragma unroll
+  for (int i = 0; i < kItemsPerThread; i++) {
+    const unsigned long long all = __ballot(valid[i]);
+    if (all != 0ull) {
+      const int first = __ffsll((long long)all) - 1;
+      const uint32_t dv = (uint32_t)__shfl((int)digit[i], first);
+      const unsigned long long same = __ballot(valid[i] && digit[i] == dv);
+      if (lane == first) atomicAdd(&s_total[dv], (uint32_t)__popcll(same));
+      if (valid[i] && digit[i] != dv) atomicAdd(&s_total[digit[i]], 1u);
+    }
+  }
+  __syncthreads();
+  const uint32_t total = tid < 256 ? s_total[tid] : 0u;
+  const int group = (int)wg / kGroup;
+  const bool closes_group = (int)wg % kGroup == kGroup - 1;
+  uint32_t in_group = 0;
+  uint32_t* const group_word = a.group_states + (size_t)group * 256 + (tid & 255);
+  if (tid < 256) {
+    __hip_atomic_store(a.states + (size_t)wg * 256 + tid, kPartial | total, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    // The workgroup that closes a group collects the group's count right away, ahead of its own
+    // ranking: every later group waits for that word.
+    if (closes_group) {
+      in_group = look_back(a.states, (int)wg - 1, group * kGroup, tid, &a.ctl[kCtlError], 1u << PASS);
+      __hip_atomic_store(group_word, kPartial | (in_group + total), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    }
+  }
+
+  STAMP(1);
+  // rank within the wave: lanes holding the same digit find each other with one ballot per digit bit
+  const u64 lanes_below = (1ull << lane) - 1ull;
+#pragma unroll
+  for (int i = 0; i < kItemsPerThread; i++) {
+    u64 same = __ballot(valid[i]);
+#pragma unroll
+    for (int bit = 0; bit < 8; bit++) {
+      const bool mine = (digit[i] >> bit) & 1u;
+      const u64 set = __ballot(mine);
+      same &= mine ? set : ~set;
+    }
+    const uint32_t before = (uint32_t)__popcll(same & lanes_below);
+    uint32_t seen = 0;
+    if (valid[i]) {
+      seen = s_count[wave][digit[i]];
+      if (before == 0) s_count[wave][digit[i]] = seen + (uint32_t)__popcll(same);
+    }
+    rank[i] = seen + before;
+  }
+  __syncthreads();
+  STAMP(2);
+
+  // per digit: offsets of the waves within the digit
+  if (tid < 256) {
+    uint32_t before = 0;
+#pragma unroll
+    for (int w = 0; w < kWaves; w++) {
+      const uint32_t c = s_count[w][tid];
+      s_count[w][tid] = before;
+      before += c;
+    }
+  }
+  // exclusive scans over the 256 digits: of the workgroup's counts (local ranks) and of the
+  // global bins (where each digit starts in the output)
+  const uint32_t incl_local = wave_incl_scan(total), incl_bin = wave_incl_scan(bin);
+  if (lane == 63 && wave < 4) { s_misc[4 + wave] = incl_local; s_misc[8 + wave] = incl_bin; }
+  __syncthreads();
+  STAMP(3);
+  if (tid < 256) {
+    uint32_t local0 = incl_local - total, bin0 = incl_bin - bin;
+    for (int w = 0; w < wave; w++) { local0 += s_misc[4 + w]; bin0 += s_misc[8 + w]; }
+    if (tid == 255) s_misc[1] = local0 + total;                     // valid items in this workgroup
+
+    // look-back: how many items with this digit sit in earlier workgroups
+    if (!closes_group)
+      in_group = look_back(a.states, (int)wg - 1, group * kGroup, tid, &a.ctl[kCtlError], 1u << PASS);
+    const uint32_t groups_before = look_back(a.group_states, group - 1, 0, tid, &a.ctl[kCtlError], 16u << PASS);
+    if (closes_group)
+      __hip_atomic_store(group_word, kComplete | (groups_before + in_group + total), __ATOMIC_RELAXED,
+                         __HIP_MEMORY_SCOPE_AGENT);
+    const uint32_t earlier = groups_before + in_group;
+    s_local[tid] = local0;
+    s_dest[tid] = bin0 + earlier - local0;
+  }
+  __syncthreads();
+  STAMP(4);
+
+  // into workgroup order
+#pragma unroll
+  for (int i = 0; i < kItemsPerThread; i++) {
+    if (valid[i]) {
+      const uint32_t r = s_local[digit[i]] + s_count[wave][digit[i]] + rank[i];
+      s_keys[r] = key[i];
+      s_vals[r] = val[i];
+    }
+  }
+  __syncthreads();
+  STAMP(5);
+  const uint32_t mine_n = s_misc[1];
+#pragma unroll
+  for (int k = 0; k < kItemsPerThread; k++) {
+    const uint32_t r = (uint32_t)(k * kThreads + tid);
+    if (r < mine_n) {
+      const uint32_t kk = s_keys[r];
+      const uint32_t dst = s_dest[(kk >> kShift) & 255u] + r;
+      if (PASS < 3) a.keys_out[dst] = kk;
+      a.vals_out[dst] = s_vals[r];
+    }
+  }
+  STAMP(6);
+}
+
+struct Layout {
+  size_t state_words, group_words;   // per pass
+  size_t clear_words;   // histogram + control + look-back words: what one launch clears
+  size_t keys_a, keys_b, vals_a, vals_b, total;   // byte offsets
+  uint32_t workgroups;
+};
+
+Layout layout(uint32_t P) {
+  Layout L;
+  const uint32_t items = (uint32_t)kThreads * (P >= kManyFrom ? kManyItems : kFewItems);
+  L.workgroups = (P + items - 1) / items;
+  L.state_words = (size_t)L.workgroups * 256;
+  L.group_words = (size_t)((L.workgroups + kGroup - 1) / kGroup) * 256;
+  L.clear_words = kHistWords + kCtlWords + 4 * (L.state_words + L.group_words);
+  size_t o = gsr::align_up(L.clear_words * 4, 256);
+  L.keys_a = o; o += gsr::align_up((size_t)P * 4, 256);
+  L.keys_b = o; o += gsr::align_up((size_t)P * 4, 256);
+  L.vals_a = o; o += gsr::align_up((size_t)P * 8, 256);
+  L.vals_b = o; o += gsr::align_up((size_t)P * 8, 256);
+  L.total = o;
+  return L;
+}
+
+}  // namespace
+
+namespace gsr {
+
+size_t depth_sort_bytes(int P) { return P > 0 ? layout((uint32_t)P).total : 256; }
+
+// sorted_vals[0 .. visible) = the values of the keys != 0xFFFFFFFF in ascending key order, equal
+// keys in input order; the rest of sorted_vals is left untouched.
+int depth_sort(int P, const uint32_t* keys, const uint64_t* vals, uint64_t* sorted_vals, void* scratch, hipStream_t st) {
+  const Layout L = layout((uint32_t)P);
+  char* base = (char*)scratch;
+  uint32_t* hist = (uint32_t*)base;
+  uint32_t* ctl = hist + kHistWords;
+  uint32_t* states = ctl + kCtlWords;
+  uint32_t* ka = (uint32_t*)(base + L.keys_a);
+  uint32_t* kb = (uint32_t*)(base + L.keys_b);
+  u64* va = (u64*)(base + L.vals_a);
+  u64* vb = (u64*)(base + L.vals_b);
+  const unsigned clear_blocks = (unsigned)((L.clear_words + 1023) / 1024 < 1024 ? (L.clear_words + 1023) / 1024 : 1024);
+  hipLaunchKernelGGL(sort_clear_kernel, dim3(clear_blocks), dim3(256), 0, st, hist, L.clear_words);
+  const unsigned hist_wanted = ((unsigned)P + 4095u) / 4096u;
+  const unsigned hist_blocks = hist_wanted < 512u ? hist_wanted : 512u;
+  hipLaunchKernelGGL(sort_histogram_kernel, dim3(hist_blocks), dim3(kThreads), 0, st, keys, (uint32_t)P, hist, ctl);
+  const dim3 grid(L.workgroups), block(kThreads);
+  const size_t per_pass = L.state_words + L.group_words;
+  auto args = [&](int pass, const uint32_t* kin, const u64* vin, uint32_t* kout, u64* vout) {
+    uint32_t* s = states + pass * per_pass;
+    return PassArgs{kin, vin, kout, vout, hist + 256 * pass, ctl, s, s + L.state_words, (uint32_t)P};
+  };
+  if ((uint32_t)P >= kManyFrom) {
+    hipLaunchKernelGGL((sort_pass_kernel<0, kManyItems>), grid, block, 0, st, args(0, keys, (const u64*)vals, ka, va));
+    hipLaunchKernelGGL((sort_pass_kernel<1, kManyItems>), grid, block, 0, st, args(1, ka, va, kb, vb));
+    hipLaunchKernelGGL((sort_pass_kernel<2, kManyItems>), grid, block, 0, st, args(2, kb, vb, ka, va));
+    hipLaunchKernelGGL((sort_pass_kernel<3, kManyItems>), grid, block, 0, st, args(3, ka, va, nullptr, (u64*)sorted_vals));
+  } else {
+    hipLaunchKernelGGL((sort_pass_kernel<0, kFewItems>), grid, block, 0, st, args(0, keys, (const u64*)vals, ka, va));
+    hipLaunchKernelGGL((sort_pass_kernel<1, kFewItems>), grid, block, 0, st, args(1, ka, va, kb, vb));
+    hipLaunchKernelGGL((sort_pass_kernel<2, kFewItems>), grid, block, 0, st, args(2, kb, vb, ka, va));
+    hipLaunchKernelGGL((sort_pass_kernel<3, kFewItems>), grid, block, 0, st, args(3, ka, va, nullptr, (u64*)sorted_vals));
+  }
+  return gsr::check_launch("depth_sort");
+}
+
+}  // namespace gsr

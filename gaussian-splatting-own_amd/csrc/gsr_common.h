@@ -66,6 +66,13 @@ inline Pack make_pack(int P, int tiles_x, int tiles_y) {
 // defined with the binning kernels.
 int launch_totals_final(int blocks, const uint32_t* partials, uint32_t* totals, hipStream_t stream);
 
+// Depth sort of the binning (defined in depthsort.hip): sorted_vals[0 .. visible) = the values whose
+// key is not 0xFFFFFFFF, by ascending key, equal keys in input order.  scratch: depth_sort_bytes(P)
+// bytes, 256-byte aligned.
+size_t depth_sort_bytes(int P);
+int depth_sort(int P, const uint32_t* keys, const uint64_t* vals, uint64_t* sorted_vals, void* scratch,
+               hipStream_t stream);
+
 }  // namespace gsr
 
 #define GSR_REQUIRE(cond, ...)                                   \

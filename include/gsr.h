@@ -130,8 +130,10 @@ int gsr_mark_visible(int P, const float* means3D, const float* viewmatrix, uint8
  * (sort_vals of stage 1), and that word is what the partitions read.
  * V, N, E1, E2 below are the totals of stage 1, read back by the caller. */
 
-/* gsr_bin_sort: sorted_vals (P) uint64 = sort_vals ordered by ascending depth
- * key, ties by ascending index (stable); the V visible ones come first. */
+/* gsr_bin_sort: sorted_vals[0 .. V) = the sort_vals of the V visible Gaussians
+ * (depth key != 0xFFFFFFFF) ordered by ascending depth key, ties by ascending
+ * index (stable).  The culled ones are dropped: sorted_vals[V .. P) is not
+ * written.  P < 2^30. */
 size_t gsr_bin_sort_bytes(int P);
 int gsr_bin_sort(int P, const uint32_t* depth_keys, const uint64_t* sort_vals,
                  uint64_t* sorted_vals, void* scratch, size_t scratch_bytes, void* stream);

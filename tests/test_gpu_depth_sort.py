@@ -1,0 +1,78 @@
+"""gsr_bin_sort through the C ABI against numpy's stable argsort: culled keys dropped, ties in
+input order, sizes around the workgroup and look-back group boundaries, both items-per-thread
+variants."""
+import numpy as np
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+
+CULLED = 0xFFFFFFFF
+
+
+def _sort(keys: np.ndarray, vals: np.ndarray) -> np.ndarray:
+    import diff_gaussian_rasterization as dgr
+    P = len(keys)
+    k = torch.from_numpy(keys.view(np.int32)).cuda()
+    v = torch.from_numpy(vals.view(np.int64)).cuda()
+    out = torch.full((P,), -0x1111111111111112, dtype=torch.int64, device="cuda")   # 0xEEEE...EE
+    nb = dgr._lib.gsr_bin_sort_bytes(P)
+    scratch = torch.empty((nb,), dtype=torch.uint8, device="cuda")
+    dgr._run("bin_sort", dgr._lib.gsr_bin_sort, P, dgr._ptr(k), dgr._ptr(v), dgr._ptr(out), dgr._ptr(scratch), nb,
+             dgr._stream())
+    torch.cuda.synchronize()
+    return out.cpu().numpy().view(np.uint64)
+
+
+def _check(keys, vals):
+    got = _sort(keys, vals)
+    order = np.argsort(keys, kind="stable")
+    order = order[keys[order] != CULLED]
+    V = len(order)
+    assert np.array_equal(got[:V], vals[order])
+    assert (got[V:] == np.uint64(0xEEEEEEEEEEEEEEEE)).all()      # nothing written behind the visible ones
+
+
+def _depth_keys(rng, P, culled_fraction, lo=0.2, hi=30.0):
+    z = rng.uniform(lo, hi, P).astype(np.float32)
+    keys = z.view(np.uint32).copy()
+    keys[rng.random(P) < culled_fraction] = CULLED
+    return keys
+
+
+@pytest.mark.parametrize("P", [1, 63, 64, 65, 4095, 4096, 4097, 65536, 65537, 300_001])
+def test_sizes_around_the_block_boundaries(P):
+    rng = np.random.default_rng(P)
+    _check(_depth_keys(rng, P, 0.2), rng.integers(0, 2**63, P, dtype=np.uint64))
+
+
+def test_one_million_keys_and_the_eight_item_variant():
+    rng = np.random.default_rng(7)
+    for P in (1_000_000, 5_000_000):
+        _check(_depth_keys(rng, P, 0.3), rng.integers(0, 2**63, P, dtype=np.uint64))
+
+
+def test_ties_keep_input_order():
+    rng = np.random.default_rng(3)
+    P = 200_000
+    keys = rng.choice(np.array([0x3F800000, 0x3F800001, 0x40000000, 0x40490FDB, CULLED], dtype=np.uint32), P)
+    _check(keys, np.arange(P, dtype=np.uint64))
+
+
+def test_all_culled_none_culled_and_arbitrary_bit_patterns():
+    rng = np.random.default_rng(5)
+    P = 70_000
+    vals = rng.integers(0, 2**63, P, dtype=np.uint64)
+    _check(np.full(P, CULLED, dtype=np.uint32), vals)
+    _check(_depth_keys(rng, P, 0.0), vals)
+    keys = rng.integers(0, 2**32 - 1, P, dtype=np.uint64).astype(np.uint32)     # every byte of the key varies
+    _check(keys, vals)
+    _check(np.full(P, 0x40A00000, dtype=np.uint32), vals)                       # one key: one digit per pass
+
+
+def test_narrow_depth_range_many_groups():
+    """All keys inside one power of two (top bytes constant) and more than 16 workgroups, so that
+    the group level of the look-back is exercised with every count in one bin."""
+    rng = np.random.default_rng(11)
+    P = 16 * 4096 * 3 + 17
+    _check(_depth_keys(rng, P, 0.1, lo=5.0, hi=5.5), rng.integers(0, 2**63, P, dtype=np.uint64))

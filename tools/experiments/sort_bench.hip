@@ -8,6 +8,9 @@
 #include <algorithm>
 #include <hip/hip_runtime.h>
 #include <rocprim/rocprim.hpp>
+#include <cstdarg>
+#include "../../gaussian-splatting-own_amd/csrc/depthsort.hip"
+namespace gsr { int fail(int code, const char* fmt, ...) { va_list ap; va_start(ap, fmt); vprintf(fmt, ap); va_end(ap); printf("\n"); return code; } }
 
 #define CK(x) do { hipError_t e_ = (x); if (e_ != hipSuccess) { printf("%s: %s\n", #x, hipGetErrorString(e_)); exit(1); } } while (0)
 typedef unsigned long long u64;
@@ -94,6 +97,47 @@ void try_own(const char* name, uint32_t P, const uint32_t* keys, uint32_t* ko, c
   CK(hipFree(tmp));
 }
 
+void try_handwritten(uint32_t P, const uint32_t* keys, const u64* vals, u64* vo, const std::vector<uint32_t>& want_k,
+                     const std::vector<u64>& want_v) {
+  const size_t bytes = gsr::depth_sort_bytes((int)P);
+  char* tmp; CK(hipMalloc(&tmp, bytes));
+  CK(hipMemset(vo, 0xEE, (size_t)P * 8));
+  gsr::depth_sort((int)P, keys, (const uint64_t*)vals, (uint64_t*)vo, tmp, 0);
+  CK(hipDeviceSynchronize());
+  uint32_t V = 0;
+  while (V < P && want_k[V] != 0xFFFFFFFFu) V++;
+  std::vector<u64> v(P);
+  CK(hipMemcpy(v.data(), vo, (size_t)P * 8, hipMemcpyDeviceToHost));
+  bool ok = true;
+  for (uint32_t i = 0; i < V && ok; i++) ok = v[i] == want_v[i];
+  for (uint32_t i = V; i < P && ok; i++) ok = v[i] == 0xEEEEEEEEEEEEEEEEull;   // untouched beyond the visible ones
+  uint32_t ctl[16];
+  CK(hipMemcpy(ctl, tmp + 4096, sizeof(ctl), hipMemcpyDeviceToHost));
+  const float ms = time_ms([&] { gsr::depth_sort((int)P, keys, (const uint64_t*)vals, (uint64_t*)vo, tmp, 0); });
+#ifdef GSR_SORT_TIMING
+  {
+    static long long t[4][512][8];
+    CK(hipMemcpyFromSymbol(t, HIP_SYMBOL(g_sort_times), sizeof(t)));
+    const int nb = (int)((P + 4095) / 4096) / (P >= 4500000u ? 2 : 1);
+    for (int pass = 0; pass < 4; pass++) {
+      long long t0 = t[pass][0][0];
+      for (int b = 0; b < nb && b < 512; b++) t0 = t[pass][b][0] < t0 ? t[pass][b][0] : t0;
+      for (int b : {0, 1, 15, 16, 100, 200, nb - 1}) {
+        if (b >= nb || b >= 512) continue;
+        printf("pass %d wg %3d start %6.2f us | load %5.2f rank %5.2f sums %5.2f lookback %5.2f place %5.2f write %5.2f\n", pass, b,
+               (t[pass][b][0] - t0) * 0.01, (t[pass][b][1] - t[pass][b][0]) * 0.01, (t[pass][b][2] - t[pass][b][1]) * 0.01,
+               (t[pass][b][3] - t[pass][b][2]) * 0.01, (t[pass][b][4] - t[pass][b][3]) * 0.01,
+               (t[pass][b][5] - t[pass][b][4]) * 0.01, (t[pass][b][6] - t[pass][b][5]) * 0.01);
+      }
+    }
+  }
+#endif
+  printf("hand-written (visible %u, counted %u, error word %u) %8.1f us  %s\n", V, ctl[0], ctl[5], ms * 1e3f,
+         ok ? "exact" : "MISMATCH");
+  fflush(stdout);
+  CK(hipFree(tmp));
+}
+
 template <class Cfg>
 void try_public(const char* name, uint32_t P, const uint32_t* keys, uint32_t* ko, const u64* vals, u64* vo) {
   size_t bytes = 0;
@@ -129,19 +173,8 @@ int main(int argc, char** argv) {
   printf("P = %u\n", P);
   using Dflt = rp::radix_sort_config<rp::default_config, rp::default_config, rp::default_config, (1u << 16)>;
   try_public<Dflt>("default", P, keys, ko, vals, vo);
-  constexpr auto B = rp::block_radix_rank_algorithm::basic;
-  constexpr auto BM = rp::block_radix_rank_algorithm::basic_memoize;
   constexpr auto M = rp::block_radix_rank_algorithm::match;
-  try_own<1024, 8, 1024, 8, M>("1024x8 match (library's)", P, keys, ko, vals, vo, wk, wv);
-  try_own<1024, 4, 1024, 4, M>("1024x4 match", P, keys, ko, vals, vo, wk, wv);
-  try_own<1024, 4, 1024, 3, M>("h1024x4 s1024x3 match", P, keys, ko, vals, vo, wk, wv);
-  try_own<1024, 4, 1024, 2, M>("h1024x4 s1024x2 match", P, keys, ko, vals, vo, wk, wv);
-  try_own<1024, 4, 1024, 6, M>("h1024x4 s1024x6 match", P, keys, ko, vals, vo, wk, wv);
-  try_own<256, 4, 1024, 4, M>("h256x4 s1024x4 match", P, keys, ko, vals, vo, wk, wv);
-  try_own<256, 16, 1024, 4, M>("h256x16 s1024x4 match", P, keys, ko, vals, vo, wk, wv);
-  try_own<512, 8, 1024, 4, M>("h512x8 s1024x4 match", P, keys, ko, vals, vo, wk, wv);
-  try_own<1024, 2, 1024, 4, M>("h1024x2 s1024x4 match", P, keys, ko, vals, vo, wk, wv);
-  try_own<1024, 4, 768, 4, M>("h1024x4 s768x4 match", P, keys, ko, vals, vo, wk, wv);
-  try_own<1024, 4, 768, 6, M>("h1024x4 s768x6 match", P, keys, ko, vals, vo, wk, wv);
+  try_own<1024, 4, 1024, 4, M>("library kernels, 1024x4", P, keys, ko, vals, vo, wk, wv);
+  try_handwritten(P, keys, vals, vo, wk, wv);
   return 0;
 }
