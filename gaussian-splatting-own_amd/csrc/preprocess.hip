@@ -284,17 +284,17 @@ __global__ void __launch_bounds__(kBlock) preprocess_fwd_kernel(FwdArgs a) {
     if (a.visible) a.visible[i] = vis ? 1 : 0;
     if (!vis) {
       a.radii[i] = 0;
-      a.tiles_touched[i] = 0;
+      if (a.tiles_touched) a.tiles_touched[i] = 0;
       a.depth_keys[i] = 0xFFFFFFFFu;
-      reinterpret_cast<uint2*>(a.rects)[i] = make_uint2(0u, 0u);
+      if (a.rects) reinterpret_cast<uint2*>(a.rects)[i] = make_uint2(0u, 0u);
       a.sort_vals[i] = (unsigned long long)(uint32_t)i;
       rec[3] = make_uint4(0u, 0u, 0u, 0u);
     } else {
       const uint32_t rmin = (uint32_t)x0 | ((uint32_t)y0 << 16), rmax = (uint32_t)x1 | ((uint32_t)y1 << 16);
       a.radii[i] = radius;
-      a.tiles_touched[i] = (uint32_t)((x1 - x0) * (y1 - y0));
+      if (a.tiles_touched) a.tiles_touched[i] = (uint32_t)((x1 - x0) * (y1 - y0));
       a.depth_keys[i] = __float_as_uint(depth);
-      reinterpret_cast<uint2*>(a.rects)[i] = make_uint2(rmin, rmax);
+      if (a.rects) reinterpret_cast<uint2*>(a.rects)[i] = make_uint2(rmin, rmax);
       a.sort_vals[i] = a.pack.pack((uint32_t)i, (uint32_t)x0, (uint32_t)x1 - 1u, (uint32_t)y0, (uint32_t)y1 - 1u);
       rec[0] = make_uint4(__float_as_uint(pxs), __float_as_uint(pys), __float_as_uint(hx), __float_as_uint(hy));
       rec[1] = make_uint4(__float_as_uint(conA), __float_as_uint(conB), __float_as_uint(conC),
@@ -677,7 +677,7 @@ extern "C" int gsr_preprocess_fwd(int P, int D, int M, const float* means3D, con
   GSR_REQUIRE(totals && ((uintptr_t)totals & 15) == 0, "preprocess_fwd: totals must be non-null and 16-byte aligned");
   if (P == 0) return gsr::launch_totals_final(0, totals + 4, totals, (hipStream_t)stream);
   GSR_REQUIRE(means3D && opacities && viewmatrix && projmatrix && campos, "preprocess_fwd: null input");
-  GSR_REQUIRE(records && radii && tiles_touched && depth_keys && rects && sort_vals, "preprocess_fwd: null output");
+  GSR_REQUIRE(records && radii && depth_keys && sort_vals, "preprocess_fwd: null output");
   GSR_REQUIRE((shs != nullptr) != (colors_precomp != nullptr), "preprocess_fwd: give exactly one of shs / colors_precomp");
   GSR_REQUIRE(((scales != nullptr) && (rotations != nullptr)) != (cov3D_precomp != nullptr),
               "preprocess_fwd: give exactly one of (scales, rotations) / cov3D_precomp");
@@ -756,7 +756,7 @@ extern "C" int gsr_preprocess_fwd_raw(int P, int D, int n_rest, const float* xyz
   if (P == 0) return gsr::launch_totals_final(0, totals + 4, totals, (hipStream_t)stream);
   GSR_REQUIRE(xyz && scaling_raw && rotation_raw && opacity_raw && features_dc && viewmatrix && projmatrix && campos,
               "preprocess_fwd_raw: null input");
-  GSR_REQUIRE(records && radii && tiles_touched && depth_keys && rects && sort_vals, "preprocess_fwd_raw: null output");
+  GSR_REQUIRE(records && radii && depth_keys && sort_vals, "preprocess_fwd_raw: null output");
   GSR_REQUIRE(D >= 0 && D <= GSR_MAX_SH_DEGREE, "preprocess_fwd_raw: SH degree %d unsupported (0..3)", D);
   GSR_REQUIRE(n_rest >= (D + 1) * (D + 1) - 1 && n_rest <= 15 && (n_rest == 0 || features_rest),
               "preprocess_fwd_raw: n_rest=%d does not hold degree %d", n_rest, D);

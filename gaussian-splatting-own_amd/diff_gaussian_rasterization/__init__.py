@@ -175,7 +175,7 @@ class GaussianRasterizationSettings(NamedTuple):
 class ForwardState:
     """Everything the forward leaves behind: op outputs, what backward needs,
     and the intermediate buffers the parity tests inspect."""
-    __slots__ = ("P", "M", "D", "W", "H", "records", "radii", "tiles_touched", "depth_keys", "sorted_vals", "rect_words",
+    __slots__ = ("P", "M", "D", "W", "H", "records", "radii", "depth_keys", "sorted_vals",
                  "num_rendered", "num_visible", "dsplat", "visible", "point_list", "ranges", "tile_ids_sorted", "color", "final_T", "n_contrib",
                  "view", "proj", "campos", "bg")
 
@@ -200,6 +200,13 @@ class ForwardState:
     def rects(self):
         r = self.records[:, 13:15]
         return torch.stack([r[:, 0] & 0xFFFF, r[:, 0] >> 16, r[:, 1] & 0xFFFF, r[:, 1] >> 16], dim=1)
+
+    @property
+    def tiles_touched(self):
+        """Tiles in each Gaussian's rectangle (0 for culled ones), from the records."""
+        r = self.rects.to(torch.int64)
+        n = (r[:, 2] - r[:, 0]) * (r[:, 3] - r[:, 1])
+        return torch.where(self.radii > 0, n, torch.zeros_like(n)).to(torch.int32)
 
     @property
     def clamped(self):
@@ -236,10 +243,8 @@ def rasterize_forward(s: GaussianRasterizationSettings, means3D, opacities, shs=
     u32 = dict(dtype=torch.int32, device=dev)   # uint32 payloads carried in int32 tensors
     st.records = torch.empty((P, REC_WORDS), **u32)
     st.radii = torch.empty((P,), **u32)
-    st.tiles_touched = torch.empty((P,), **u32)
     st.depth_keys = torch.empty((P,), **u32)
     st.sorted_vals = torch.empty((P,), dtype=torch.int64, device=dev)   # packed (index, rectangle), front to back
-    st.rect_words = torch.empty((P, 2), **u32)
     st.visible = torch.empty((P,), dtype=torch.bool, device=dev)      # radii > 0, written by the preprocess kernel
     gx, gy = (W + TILE - 1) // TILE, (H + TILE - 1) // TILE
     st.ranges = torch.empty((gx * gy, 2), **u32)
@@ -253,7 +258,7 @@ def rasterize_forward(s: GaussianRasterizationSettings, means3D, opacities, shs=
     if P > 0:
         totals = torch.empty((_lib.gsr_totals_words(P),), **u32)
         sort_vals = torch.empty((P,), dtype=torch.int64, device=dev)
-        outs = (_ptr(st.records), _ptr(st.radii), _ptr(st.tiles_touched), _ptr(st.depth_keys), _ptr(st.rect_words),
+        outs = (_ptr(st.records), _ptr(st.radii), None, _ptr(st.depth_keys), None,
                 _ptr(sort_vals), _ptr(totals), _ptr(st.visible), stream)
         if raw is not None:
             r = {k: _f32(v, k) for k, v in raw.items()}

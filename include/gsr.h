@@ -84,10 +84,11 @@ const char* gsr_last_error(void);
  * cov3D_precomp is non-NULL.  D = active SH degree (0..3), M = coefficients
  * stored per Gaussian and channel (>= (D+1)^2).
  * Outputs: records (P,16) words; radii (P) int32 (0 = not visible);
- * tiles_touched (P) uint32; depth_keys (P) uint32 = IEEE bits of view z for
- * visible Gaussians, 0xFFFFFFFF for culled ones; rects (P,2) uint32 = the tile
- * rectangle as in the record (min, exclusive max; x | y << 16), zeros for
- * culled Gaussians; and what the binning starts from:
+ * depth_keys (P) uint32 = IEEE bits of view z for visible Gaussians, 0xFFFFFFFF
+ * for culled ones; optionally (NULL = not wanted; nothing downstream reads them)
+ * tiles_touched (P) uint32 and rects (P,2) uint32 = the tile rectangle as in the
+ * record (min, exclusive max; x | y << 16), zeros for culled Gaussians; and what
+ * the binning starts from:
  * sort_vals (P) uint64 = the Gaussian's index packed with its tile rectangle
  * (bit widths chosen from P and the tile grid; the call fails if they exceed
  * 64 bits, e.g. more than 2^24 Gaussians on a grid of more than 1024x1024
