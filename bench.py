@@ -157,15 +157,23 @@ def main():
         loss = photometric_loss(out["render"], gt)
         loss.backward()
         if use_dist:
+            # RCCL over xGMI: one fp32 scalar.  Nothing in the next step needs the mean loss, so the
+            # collective runs on RCCL's own stream beside it; the previous one is waited for first, so
+            # at most one is outstanding, and the last one before the closing barrier.
+            if step.pending is not None:
+                step.pending[0].wait()
             lv = loss.detach().clone()
-            dist.all_reduce(lv)                                       # RCCL over xGMI: one fp32 scalar
-            lv /= world
+            step.pending = (dist.all_reduce(lv, async_op=True), lv)
         if args.dp_grads:
             step.grad_scale = all_reduce_gradients(opt.params)        # RCCL over xGMI: 59 floats per Gaussian
         return out
     step.grad_scale = 1.0
+    step.pending = None
 
     def barrier():
+        if step.pending is not None:
+            step.pending[0].wait()
+            step.pending = None
         torch.cuda.synchronize()
         if use_dist:
             dist.barrier()
