@@ -99,6 +99,9 @@ def main():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--unfused", action="store_true",
                     help="apply the model's activations with PyTorch ops, as the reference does, instead of in-kernel")
+    ap.add_argument("--short-lists", action="store_true",
+                    help="bin each Gaussian only into the tiles its alpha >= 1/255 ellipse's bounding box reaches "
+                         "(same images and gradients; not the reference's internal lists)")
     ap.add_argument("--dp-grads", action="store_true",
                     help="data-parallel training: all-reduce the gradients of all ranks (one flat buffer, RCCL) "
                          "inside the timed step, instead of the scalar loss only")
@@ -119,6 +122,8 @@ def main():
         print(f"warning: --gpus {args.gpus} but WORLD_SIZE {world}", file=sys.stderr)
 
     import diff_gaussian_rasterization as dgr
+    if args.short_lists:
+        dgr.REFERENCE_LISTS = False
     from gsplat_host.cameras import orbit_camera
     from gsplat_host.loss import photometric_loss
     from gsplat_host.model import GaussianParams
@@ -245,7 +250,8 @@ def main():
             "config": {"workload": f"{args.workload}: {P} Gaussians, {W}x{H}, SH degree {deg}, full train step "
                                    "(activations + render + 0.8*L1+0.2*(1-SSIM) + backward), one view per GPU",
                        "gaussians": P, "visible": N, "tile_instances": st_N, "views_per_step": world,
-                       "activations": "torch ops (as the reference)" if args.unfused else "in the preprocess kernels"},
+                       "activations": "torch ops (as the reference)" if args.unfused else "in the preprocess kernels",
+                       "tile_lists": "short (ellipse bounding boxes)" if args.short_lists else "the reference's"},
             "train_step_ms": round(ms_per_step, 3), "render_ms": round(render_ms, 3),
             "roofline": {"bound": "hbm", "kernel": dominant, "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS,
                          "unit": "GB/s", "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": traffic,

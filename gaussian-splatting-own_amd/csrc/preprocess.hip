@@ -196,7 +196,7 @@ __device__ __forceinline__ float quat_norm(const float* q) {
 }
 
 struct FwdArgs {
-  int raw, n_rest, P, M, W, H;
+  int raw, n_rest, reference_lists, P, M, W, H;
   const float* means3D; const float* scales; const float* rotations; const float* opacities;
   const float* shs; const float* shs_rest; const float* colors_precomp;
   const float* cov3D_precomp; const float* view; const float* proj; const float* campos;
@@ -216,8 +216,9 @@ template <int D>
 __global__ void __launch_bounds__(kBlock) preprocess_fwd_kernel(FwdArgs a) {
   __shared__ uint32_t s_part[kBlock / 64][4];
   const int i = blockIdx.x * kBlock + threadIdx.x;
-  bool vis = false;
+  bool vis = false, binned = false;
   int radius = 0, x0 = 0, y0 = 0, x1 = 0, y1 = 0;
+  int bx0 = 0, by0 = 0, bx1 = 0, by1 = 0;   // the rectangle the tile lists are built from
   float pxs = 0.f, pys = 0.f, conA = 0.f, conB = 0.f, conC = 0.f, hx = -1.f, hy = -1.f;
   float opacity = 0.f, depth = 0.f;
   if (i < a.P) {
@@ -278,6 +279,22 @@ __global__ void __launch_bounds__(kBlock) preprocess_fwd_kernel(FwdArgs a) {
           hx = sqrtf(tau * e.a) * 1.0005f + 0.01f;
           hy = sqrtf(tau * e.c) * 1.0005f + 0.01f;
         }
+        // The module bins every tile of the 3-sigma rectangle.  A pixel can blend the splat only
+        // inside that ellipse, so tiles of the rectangle that its bounding box misses hold no
+        // contribution: unless the module's own lists are asked for they are left out (images,
+        // radii and gradients do not change; the lists get shorter, a third at typical opacities).
+        bx0 = x0; by0 = y0; bx1 = x1; by1 = y1;
+        if (!a.reference_lists) {
+          if (hx < 0.0f) {
+            bx1 = bx0;
+          } else {
+            bx0 = max(bx0, (int)fminf((float)gx, fmaxf(0.0f, floorf((pxs - hx) / (float)GSR_TILE_X))));
+            by0 = max(by0, (int)fminf((float)gy, fmaxf(0.0f, floorf((pys - hy) / (float)GSR_TILE_Y))));
+            bx1 = min(bx1, (int)fminf((float)gx, fmaxf(0.0f, floorf((pxs + hx) / (float)GSR_TILE_X) + 1.0f)));
+            by1 = min(by1, (int)fminf((float)gy, fmaxf(0.0f, floorf((pys + hy) / (float)GSR_TILE_Y) + 1.0f)));
+          }
+        }
+        binned = vis && bx1 > bx0 && by1 > by0;
       }
     }
     uint4* rec = reinterpret_cast<uint4*>(a.records) + (size_t)i * 4;
@@ -293,9 +310,10 @@ __global__ void __launch_bounds__(kBlock) preprocess_fwd_kernel(FwdArgs a) {
       const uint32_t rmin = (uint32_t)x0 | ((uint32_t)y0 << 16), rmax = (uint32_t)x1 | ((uint32_t)y1 << 16);
       a.radii[i] = radius;
       if (a.tiles_touched) a.tiles_touched[i] = (uint32_t)((x1 - x0) * (y1 - y0));
-      a.depth_keys[i] = __float_as_uint(depth);
+      a.depth_keys[i] = binned ? __float_as_uint(depth) : 0xFFFFFFFFu;
       if (a.rects) reinterpret_cast<uint2*>(a.rects)[i] = make_uint2(rmin, rmax);
-      a.sort_vals[i] = a.pack.pack((uint32_t)i, (uint32_t)x0, (uint32_t)x1 - 1u, (uint32_t)y0, (uint32_t)y1 - 1u);
+      a.sort_vals[i] = binned ? a.pack.pack((uint32_t)i, (uint32_t)bx0, (uint32_t)bx1 - 1u, (uint32_t)by0, (uint32_t)by1 - 1u)
+                              : (unsigned long long)(uint32_t)i;
       rec[0] = make_uint4(__float_as_uint(pxs), __float_as_uint(pys), __float_as_uint(hx), __float_as_uint(hy));
       rec[1] = make_uint4(__float_as_uint(conA), __float_as_uint(conB), __float_as_uint(conC),
                           __float_as_uint(opacity));
@@ -334,12 +352,12 @@ __global__ void __launch_bounds__(kBlock) preprocess_fwd_kernel(FwdArgs a) {
   // list sizes of the binning (tile instances, supercell entries, cell entries, visible Gaussians):
   // one partial record per block, summed by a second small kernel; no atomics
   uint32_t n = 0, e1 = 0, e2 = 0, v = 0;
-  if (vis) {
-    const uint32_t strips = (uint32_t)((x1 - 1) / GSR_SUPERCELL - x0 / GSR_SUPERCELL + 1);
-    const uint32_t bands = (uint32_t)((y1 - 1) / GSR_SUPERCELL - y0 / GSR_SUPERCELL + 1);
-    n = (uint32_t)((x1 - x0) * (y1 - y0));
+  if (binned) {
+    const uint32_t strips = (uint32_t)((bx1 - 1) / GSR_SUPERCELL - bx0 / GSR_SUPERCELL + 1);
+    const uint32_t bands = (uint32_t)((by1 - 1) / GSR_SUPERCELL - by0 / GSR_SUPERCELL + 1);
+    n = (uint32_t)((bx1 - bx0) * (by1 - by0));
     e1 = strips * bands;
-    e2 = strips * (uint32_t)(y1 - y0);
+    e2 = strips * (uint32_t)(by1 - by0);
     v = 1u;
   }
   n = wave_sum_u32(n); e1 = wave_sum_u32(e1); e2 = wave_sum_u32(e2); v = wave_sum_u32(v);
@@ -668,7 +686,7 @@ extern "C" int gsr_preprocess_fwd(int P, int D, int M, const float* means3D, con
                                   float scale_modifier, const float* rotations, const float* opacities,
                                   const float* shs, const float* colors_precomp, const float* cov3D_precomp,
                                   const float* viewmatrix, const float* projmatrix, const float* campos,
-                                  int W, int H, float tanfovx, float tanfovy, int prefiltered,
+                                  int W, int H, float tanfovx, float tanfovy, int prefiltered, int reference_lists,
                                   uint32_t* records, int32_t* radii, uint32_t* tiles_touched,
                                   uint32_t* depth_keys, uint32_t* rects, uint64_t* sort_vals, uint32_t* totals,
                                   uint8_t* visible, void* stream) {
@@ -686,7 +704,7 @@ extern "C" int gsr_preprocess_fwd(int P, int D, int M, const float* means3D, con
   GSR_REQUIRE(W <= 16 * 16 * 255 && H <= 16 * 16 * 255, "preprocess_fwd: image %dx%d too large", W, H);
   const gsr::Pack pack = gsr::make_pack(P, gsr::div_up(W, GSR_TILE_X), gsr::div_up(H, GSR_TILE_Y));
   GSR_REQUIRE(pack.bits() <= 64, "preprocess_fwd: %d Gaussians on a %dx%d image do not fit the 64-bit sort value", P, W, H);
-  FwdArgs a{0, 0, P, M, W, H, means3D, scales, rotations, opacities, shs, nullptr, colors_precomp, cov3D_precomp,
+  FwdArgs a{0, 0, reference_lists, P, M, W, H, means3D, scales, rotations, opacities, shs, nullptr, colors_precomp, cov3D_precomp,
             viewmatrix, projmatrix, campos, scale_modifier, tanfovx, tanfovy, pack, records, radii, tiles_touched,
             depth_keys, rects, (unsigned long long*)sort_vals, nullptr, visible};
   return launch_preprocess_fwd("preprocess_fwd", a, D, totals, stream);
@@ -748,7 +766,8 @@ extern "C" int gsr_preprocess_fwd_raw(int P, int D, int n_rest, const float* xyz
                                       float scale_modifier, const float* rotation_raw, const float* opacity_raw,
                                       const float* features_dc, const float* features_rest,
                                       const float* viewmatrix, const float* projmatrix, const float* campos, int W,
-                                      int H, float tanfovx, float tanfovy, uint32_t* records, int32_t* radii,
+                                      int H, float tanfovx, float tanfovy, int reference_lists, uint32_t* records,
+                                      int32_t* radii,
                                       uint32_t* tiles_touched, uint32_t* depth_keys, uint32_t* rects,
                                       uint64_t* sort_vals, uint32_t* totals, uint8_t* visible, void* stream) {
   GSR_REQUIRE(P >= 0 && W > 0 && H > 0, "preprocess_fwd_raw: bad sizes P=%d W=%d H=%d", P, W, H);
@@ -765,7 +784,7 @@ extern "C" int gsr_preprocess_fwd_raw(int P, int D, int n_rest, const float* xyz
   GSR_REQUIRE(pack.bits() <= 64, "preprocess_fwd_raw: %d Gaussians on a %dx%d image do not fit the 64-bit sort value", P,
               W, H);
   // with no rest tensor the dc tensor alone is a (P,1,3) shs tensor
-  FwdArgs a{1, n_rest, P, 1 + n_rest, W, H, xyz, scaling_raw, rotation_raw, opacity_raw, features_dc,
+  FwdArgs a{1, n_rest, reference_lists, P, 1 + n_rest, W, H, xyz, scaling_raw, rotation_raw, opacity_raw, features_dc,
             n_rest > 0 ? features_rest : nullptr, nullptr, nullptr, viewmatrix, projmatrix, campos, scale_modifier,
             tanfovx, tanfovy, pack, records, radii, tiles_touched, depth_keys, rects, (unsigned long long*)sort_vals,
             nullptr, visible};

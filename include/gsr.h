@@ -100,14 +100,25 @@ const char* gsr_last_error(void);
  * scratch) and is 16-byte aligned.
  *
  * visible (P) uint8, optional (may be NULL): radii > 0, the `visibility_filter`
- * render() returns (gaussian_renderer/__init__.py:99). */
+ * render() returns (gaussian_renderer/__init__.py:99).
+ *
+ * reference_lists: which tiles a Gaussian is binned into.  Non-zero (what the
+ * Python module passes unless told otherwise): every tile of its 3-sigma
+ * rectangle, as the module's duplicateWithKeys does; the tile lists, keys and
+ * ranges of stage 2 are then the module's, bit for bit.  Zero:
+ * only the tiles of that rectangle which the bounding box of its
+ * alpha >= 1/255 ellipse reaches (no pixel outside that box can blend it):
+ * shorter lists, the same images, radii and gradients.  A Gaussian whose box
+ * reaches no tile keeps its radius and its place in `visible`, gets the culled
+ * depth key and is not counted in totals[3].  records, radii, tiles_touched and
+ * rects are the same in both modes. */
 size_t gsr_totals_words(int P);
 int gsr_preprocess_fwd(int P, int D, int M, const float* means3D, const float* scales,
                        float scale_modifier, const float* rotations, const float* opacities,
                        const float* shs, const float* colors_precomp, const float* cov3D_precomp,
                        const float* viewmatrix, const float* projmatrix, const float* campos,
                        int W, int H, float tanfovx, float tanfovy, int prefiltered,
-                       uint32_t* records, int32_t* radii, uint32_t* tiles_touched,
+                       int reference_lists, uint32_t* records, int32_t* radii, uint32_t* tiles_touched,
                        uint32_t* depth_keys, uint32_t* rects, uint64_t* sort_vals,
                        uint32_t* totals, uint8_t* visible, void* stream);
 
@@ -206,10 +217,10 @@ int gsr_preprocess_fwd_raw(int P, int D, int n_rest, const float* xyz, const flo
                            float scale_modifier, const float* rotation_raw, const float* opacity_raw,
                            const float* features_dc, const float* features_rest,
                            const float* viewmatrix, const float* projmatrix, const float* campos,
-                           int W, int H, float tanfovx, float tanfovy, uint32_t* records,
-                           int32_t* radii, uint32_t* tiles_touched, uint32_t* depth_keys,
-                           uint32_t* rects, uint64_t* sort_vals, uint32_t* totals, uint8_t* visible,
-                           void* stream);
+                           int W, int H, float tanfovx, float tanfovy, int reference_lists,
+                           uint32_t* records, int32_t* radii, uint32_t* tiles_touched,
+                           uint32_t* depth_keys, uint32_t* rects, uint64_t* sort_vals,
+                           uint32_t* totals, uint8_t* visible, void* stream);
 int gsr_preprocess_bwd_raw(int P, int D, int n_rest, const float* xyz, const float* scaling_raw,
                            float scale_modifier, const float* rotation_raw, const float* opacity_raw,
                            const float* features_dc, const float* features_rest,

@@ -28,7 +28,7 @@ def test_c2_against_oracle(oracle32):
     ref = oracle32.forward(s_cpu, **cn)
     c = cloud.to("cuda")
     st = dgr.rasterize_forward(s_gpu, c.xyz, c.opacity, shs=c.features, scales=c.scaling, rotations=c.rotation,
-                               keep_tile_ids=True)
+                               keep_tile_ids=True, reference_lists=True)
     torch.cuda.synchronize()
     print("C2: visible", int((ref["radii"] > 0).sum()), "instances", ref["bin"]["n_dup"], flush=True)
     assert np.array_equal(st.radii.cpu().numpy(), ref["radii"])
@@ -61,7 +61,7 @@ def c3():
     s = _gpu_settings(cam, bg, deg, 1.0)
     c = cloud.to("cuda")
     st = dgr.rasterize_forward(s, c.xyz, c.opacity, shs=c.features, scales=c.scaling, rotations=c.rotation,
-                               keep_tile_ids=True)
+                               keep_tile_ids=True, reference_lists=True)
     torch.cuda.synchronize()
     return dgr, s, c, st
 
@@ -98,7 +98,8 @@ def test_c3_lists_are_sorted_and_partition_the_instances(c3):
 
 def test_c3_forward_is_deterministic_and_bounded(c3):
     dgr, s, c, st = c3
-    st2 = dgr.rasterize_forward(s, c.xyz, c.opacity, shs=c.features, scales=c.scaling, rotations=c.rotation)
+    st2 = dgr.rasterize_forward(s, c.xyz, c.opacity, shs=c.features, scales=c.scaling, rotations=c.rotation,
+                                reference_lists=True)
     torch.cuda.synchronize()
     assert torch.equal(st2.color, st.color) and torch.equal(st2.n_contrib, st.n_contrib)
     assert torch.equal(st2.point_list, st.point_list) and torch.equal(st2.ranges, st.ranges)
@@ -109,6 +110,27 @@ def test_c3_forward_is_deterministic_and_bounded(c3):
     gx, gy = (s.image_width + 15) // 16, (s.image_height + 15) // 16
     per_pixel_cap = cnt.reshape(gy, gx).repeat_interleave(16, 0).repeat_interleave(16, 1)[:s.image_height, :s.image_width]
     assert bool((st.n_contrib.to(torch.int64) <= per_pixel_cap).all())
+
+
+def test_c3_short_lists_give_the_same_image_and_gradients(c3):
+    """The optional short lists against the module's own lists at full size: identical pixels,
+    gradients equal up to the summation order of the float atomics."""
+    dgr, s, c, st = c3
+    short = dgr.rasterize_forward(s, c.xyz, c.opacity, shs=c.features, scales=c.scaling, rotations=c.rotation,
+                                  reference_lists=False)
+    torch.cuda.synchronize()
+    print("C3 instances", st.num_rendered, "->", short.num_rendered, flush=True)
+    assert short.num_rendered < st.num_rendered
+    assert torch.equal(short.color, st.color) and torch.equal(short.final_T, st.final_T)
+    assert torch.equal(short.radii, st.radii)
+    d = torch.randn(st.color.shape, device="cuda", generator=torch.Generator(device="cuda").manual_seed(3))
+    kw = dict(shs=c.features, scales=c.scaling, rotations=c.rotation)
+    g_full = dgr.rasterize_backward(s, st, d, c.xyz, **kw)
+    g_short = dgr.rasterize_backward(s, short, d, c.xyz, **kw)
+    for nm in ("means3D", "means2D", "shs", "opacities", "scales", "rotations"):
+        err = float((g_short[nm] - g_full[nm]).abs().max() / (g_full[nm].abs().max() + 1e-20))
+        print("C3 short lists", nm, "%.2e" % err, flush=True)
+        assert err < 2e-5
 
 
 def test_c3_backward_is_linear_in_the_incoming_gradient(c3):
@@ -139,7 +161,7 @@ def test_c3_interchangeable_input_paths(c3):
     d = d / d.norm(dim=1, keepdim=True)
     col = torch.clamp_min(eval_sh(3, c.features.transpose(1, 2), d) + 0.5, 0.0)
     cov = covariance_from_scaling_rotation(c.scaling, 1.0, c.rotation)
-    st2 = dgr.rasterize_forward(s, c.xyz, c.opacity, colors_precomp=col, cov3D_precomp=cov)
+    st2 = dgr.rasterize_forward(s, c.xyz, c.opacity, colors_precomp=col, cov3D_precomp=cov, reference_lists=True)
     torch.cuda.synchronize()
     assert float((st2.radii != st.radii).float().mean()) < 1e-4
     diff = (st2.color - st.color).abs()

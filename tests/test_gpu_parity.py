@@ -63,7 +63,7 @@ LOOSE = {"needles": 30.0}      # factor on the blend tolerances
 LOOSE_GEOMETRY = {"needles": 300.0}   # ... and on gradients that pass through the inverse of a near-singular 2x2
 
 
-def _run_case(oracle32, name):
+def _run_case(oracle32, name, reference_lists=True):
     import diff_gaussian_rasterization as dgr
     P, W, H, deg, coeffs, bgc, mod, kw = CASES[name]
     cloud, cam, bg, _ = make_scene(P, W, H, sh_degree=deg, seed=11, bg=bgc, coeffs=coeffs, **kw)
@@ -73,7 +73,7 @@ def _run_case(oracle32, name):
     s_gpu = _gpu_settings(cam, bg, deg, mod)
     c = cloud.to("cuda")
     st = dgr.rasterize_forward(s_gpu, c.xyz, c.opacity, shs=c.features, scales=c.scaling, rotations=c.rotation,
-                               keep_tile_ids=True)
+                               keep_tile_ids=True, reference_lists=reference_lists)
     torch.cuda.synchronize()
     return cloud, cam, bg, mod, s_cpu, s_gpu, cn, ref, st
 
@@ -115,6 +115,42 @@ def test_forward_stages(oracle32, name):
     assert diff.max() < 2e-2                       # a flipped decision moves a pixel by one contribution at most
     assert np.array_equal(st.n_contrib.cpu().numpy().view(np.uint32)[safe], fw["n_contrib"][safe])
     np.testing.assert_allclose(st.final_T.cpu().numpy()[safe], fw["final_T"][safe], rtol=2e-5 * loose, atol=1e-7)
+
+
+@pytest.mark.parametrize("name", list(CASES))
+def test_forward_with_short_lists(oracle32, name):
+    """The optional short lists leave out the tiles that the bounding box of a Gaussian's
+    alpha >= 1/255 ellipse cannot reach: every list is the module's list with entries removed (same
+    order), and the image is the one the module's lists give, bit for bit."""
+    import diff_gaussian_rasterization as dgr
+    cloud, cam, bg, mod, s_cpu, s_gpu, cn, ref, st = _run_case(oracle32, name, reference_lists=False)
+    c = cloud.to("cuda")
+    full = dgr.rasterize_forward(s_gpu, c.xyz, c.opacity, shs=c.features, scales=c.scaling, rotations=c.rotation,
+                                 keep_tile_ids=True, reference_lists=True)
+    torch.cuda.synchronize()
+    print(name, "instances", full.num_rendered, "->", st.num_rendered, flush=True)
+    assert 0 < st.num_rendered <= full.num_rendered
+    assert torch.equal(st.radii, full.radii) and torch.equal(st.visible, full.visible)
+    assert torch.equal(st.records[st.radii > 0], full.records[full.radii > 0])
+    # same pixels, bit for bit: what was left out contributed to no pixel
+    assert torch.equal(st.color, full.color)
+    assert torch.equal(st.final_T, full.final_T)
+    # subsequence of the module's lists: (tile, Gaussian) pairs all present there, still in (tile, depth, index) order
+    P = st.P
+    got = st.tile_ids_sorted.to(torch.int64) * P + st.point_list.to(torch.int64)
+    want = full.tile_ids_sorted.to(torch.int64) * P + full.point_list.to(torch.int64)
+    assert bool(torch.isin(got, want).all())
+    keys = st.sort_keys()
+    assert bool((keys[1:] >= keys[:-1]).all())
+    tie = keys[1:] == keys[:-1]
+    assert bool((st.point_list[1:][tie] > st.point_list[:-1][tie]).all())
+    r = st.ranges.to(torch.int64)
+    assert int((r[:, 1] - r[:, 0]).sum()) == st.num_rendered
+    # and against the oracle, as in the test above
+    fw = ref["fwd"]
+    safe = fw["margin"] >= MARGIN_SAFE
+    diff = np.abs(st.color.cpu().numpy() - fw["color"])
+    assert diff[:, safe].max() <= PIX_TOL * LOOSE.get(name, 1.0)
 
 
 def _rel_err(got, ref):
