@@ -90,6 +90,17 @@ def measured_traffic(workload):
         return {}
 
 
+def measured_valu(workload):
+    """Vector-ALU counters per launch from the same committed counter runs, or {}."""
+    path = os.path.join(ROOT, "profiles", "r01_traffic.json")
+    try:
+        with open(path) as f:
+            t = json.load(f)
+        return t.get("valu", {}) if t.get("workload") == workload else {}
+    except (OSError, ValueError):
+        return {}
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -242,6 +253,13 @@ def main():
         kernels["binning_total"] = {"ms": round(bin_ms, 4), "published_chain_GB": round(pub / 1e9, 4),
                                     "GBps_vs_published_chain": round(pub / (bin_ms * 1e-3) / 1e9, 1)}
         traffic = measured_traffic(args.workload).get(dominant)
+        valu = measured_valu(args.workload).get(dominant)
+        valu_note = None
+        if valu:
+            # SQ_ACTIVE_INST_VALU counts quad-cycles over all 1024 SIMDs (256 CUs x 4)
+            busy = 4.0 * valu["active_quad_cycles"] / 1024.0 / (stage_ms[dominant] * 1e-3 * 2.4e9)
+            valu_note = {"wave_instructions": valu["wave_instructions"], "busy_frac_at_2.4GHz": round(busy, 3),
+                         "source": "profiles/r01_traffic.json (rocprofv3 SQ_INSTS_VALU, SQ_ACTIVE_INST_VALU)"}
         line = {
             "metric": "train-step ms + render Msplats/s @1080p, 1M Gaussians, 1/2/4/8 MI355X",
             "value": round(msplats, 2), "unit": "Msplats/s", "n_gpus": world, "steps": args.steps,
@@ -256,7 +274,9 @@ def main():
             "roofline": {"bound": "hbm", "kernel": dominant, "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS,
                          "unit": "GB/s", "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": traffic,
                          "traffic_unit": "bytes/launch (rocprofv3 FETCH_SIZE x2 + WRITE_SIZE, profiles/r01_traffic.json)",
-                         "algorithmic_bytes": alg[dominant]},
+                         "algorithmic_bytes": alg[dominant], "valu": valu_note,
+                         "limited_by": "vector-instruction issue (VALU), not HBM" if valu_note and
+                                       valu_note["busy_frac_at_2.4GHz"] > 0.8 else None},
             "kernels": kernels,
             "optimizer": {"what": "fused Adam over the six parameter tensors, outside the timed step as in the reference",
                           "ms": round(adam_ms, 4), "parameters": n_params,
