@@ -237,7 +237,6 @@ __global__ void __launch_bounds__(Level<LEVEL>::kThreads) partition_kernel(Level
       fy[j] = LEVEL == 1 ? f / FX : 0u;
       run[j] = (WRITE && real) ? a.counts[slot0 + f * np] : 0u;
     }
-#pragma unroll 4
     for (uint32_t base = 0; base < len; base += 64) {
       const uint32_t w = s_box[base + lane];
       const uint32_t lo = w & 0xffu, wd = (w >> 8) & 0xffu, lo2 = (w >> 16) & 0xffu, wd2 = w >> 24;

@@ -29,6 +29,7 @@ constexpr int kOut = 4;                  // outputs per thread along the filter 
 constexpr int kNeed = kOut + 2 * kR;     // 14 inputs for them
 constexpr int kHTasks = kIH * (kTX / kOut);          // horizontal pass: 42 rows x 8 column groups
 constexpr int kVTasks = kTX * (kTY / kOut);          // vertical pass: 32 columns x 8 row groups
+static_assert(kVTasks == 256, "the vertical pass gives every thread of the block exactly one task");
 constexpr int kLoads = (kIH * kIW + 255) / 256;      // halo elements per thread
 
 struct Window { float w[kTaps]; };
