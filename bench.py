@@ -271,6 +271,7 @@ def main():
                        "activations": "torch ops (as the reference)" if args.unfused else "in the preprocess kernels",
                        "tile_lists": "short (ellipse bounding boxes)" if args.short_lists else "the reference's"},
             "train_step_ms": round(ms_per_step, 3), "render_ms": round(render_ms, 3),
+            "render_Ginstances_per_s": round(world * st_N / (render_ms * 1e-3) / 1e9, 2),
             "roofline": {"bound": "hbm", "kernel": dominant, "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS,
                          "unit": "GB/s", "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": traffic,
                          "traffic_unit": "bytes/launch (rocprofv3 FETCH_SIZE x2 + WRITE_SIZE, profiles/r01_traffic.json)",
