@@ -271,6 +271,59 @@ __global__ void __launch_bounds__(Level<LEVEL>::kThreads) partition_kernel(Level
   }
 }
 
+// Level 1 counts without a sweep over the buckets.  An entry covers a rectangle of supercells
+// [bx0, bx1] x [by0, by1], so the number of entries covering supercell (fx, fy) is a 2-D prefix
+// sum: add +1 / -1 at the four corners (bx0, by0), (bx1 + 1, by0), (bx0, by1 + 1),
+// (bx1 + 1, by1 + 1) of a small LDS array with atomics, then sum along x and down y.  Work per
+// entry is constant instead of proportional to the number of supercells.  (Levels 2 and 3 keep
+// the sweep: with only 16 buckets the 64 lanes of a wave collide on the same few LDS words and
+// the atomics take as long as the sweep.)
+constexpr uint32_t kMaxDiffCells = 1024;   // (supercells in x + 1) * (supercells in y + 1) must fit
+
+__global__ void __launch_bounds__(Level<1>::kThreads) count1_kernel(LevelArgs a) {
+  constexpr uint32_t L = Level<1>::kPiece;
+  constexpr int T = Level<1>::kThreads;
+  constexpr int kIter = (int)L / T;
+  __shared__ int s_d[kMaxDiffCells];
+  const uint32_t np = (a.V + L - 1) / L;
+  if (blockIdx.x >= np) return;
+  const uint32_t start = blockIdx.x * L, len = min(L, a.V - start);
+  const uint32_t FX = (uint32_t)a.g.sx, FY = (uint32_t)a.g.sy, stride = FX + 1u, rows = FY + 1u;
+  for (uint32_t i = threadIdx.x; i < stride * rows; i += T) s_d[i] = 0;
+  u64 en[kIter];
+#pragma unroll
+  for (int it = 0; it < kIter; it++) {
+    const uint32_t i = it * T + threadIdx.x;
+    en[it] = i < len ? a.in[start + i] : 0ull;
+  }
+  __syncthreads();
+#pragma unroll
+  for (int it = 0; it < kIter; it++) {
+    if (it * T + threadIdx.x < len) {
+      uint32_t x0, x1, y0, y1;
+      a.pk.rect(en[it], x0, x1, y0, y1);
+      const uint32_t bx0 = x0 / kSuper, bx1 = x1 / kSuper + 1u, by0 = y0 / kSuper, by1 = y1 / kSuper + 1u;
+      atomicAdd(&s_d[by0 * stride + bx0], 1);
+      atomicAdd(&s_d[by0 * stride + bx1], -1);
+      atomicAdd(&s_d[by1 * stride + bx0], -1);
+      atomicAdd(&s_d[by1 * stride + bx1], 1);
+    }
+  }
+  __syncthreads();
+  if (threadIdx.x < rows) {
+    int run = 0;
+    for (uint32_t x = 0; x < stride; x++) { run += s_d[threadIdx.x * stride + x]; s_d[threadIdx.x * stride + x] = run; }
+  }
+  __syncthreads();
+  if (threadIdx.x < stride) {
+    int run = 0;
+    for (uint32_t y = 0; y < rows; y++) { run += s_d[y * stride + threadIdx.x]; s_d[y * stride + threadIdx.x] = run; }
+  }
+  __syncthreads();
+  for (uint32_t f = threadIdx.x; f < FX * FY; f += T)
+    a.counts[blockIdx.x + f * np] = (uint32_t)s_d[(f / FX) * stride + f % FX];
+}
+
 // ---------------------------------------------------------------------------
 // prefix sums between the sweeps: one block each
 // ---------------------------------------------------------------------------
@@ -539,7 +592,10 @@ extern "C" int gsr_bin_lists(int P, uint32_t V, uint32_t N, uint32_t E1, uint32_
   a.in = (const u64*)sorted_vals;
   a.counts = (uint32_t*)(base + L.counts1);
   a.out64 = (u64*)(base + L.entries1);
-  hipLaunchKernelGGL((partition_kernel<1, false>), dim3(L.pieces1), dim3(Level<1>::kThreads), 0, st, a);
+  if ((uint32_t)(g.sx + 1) * (uint32_t)(g.sy + 1) <= kMaxDiffCells)
+    hipLaunchKernelGGL(count1_kernel, dim3(L.pieces1), dim3(Level<1>::kThreads), 0, st, a);
+  else
+    hipLaunchKernelGGL((partition_kernel<1, false>), dim3(L.pieces1), dim3(Level<1>::kThreads), 0, st, a);
   hipLaunchKernelGGL(scan1_kernel, dim3(1), dim3(kScanBlock), 0, st, g, V, a.counts, (uint32_t*)(base + L.list_start2),
                      (uint32_t*)(base + L.list_len2), (uint32_t*)(base + L.piece_first2), (uint4*)(base + L.desc2));
   hipLaunchKernelGGL((partition_kernel<1, true>), dim3(L.pieces1), dim3(Level<1>::kThreads), 0, st, a);
