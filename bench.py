@@ -6,8 +6,8 @@
 One "step" is the reference's own timed span of a training iteration
 (train.py:67-95): model activations -> render() -> 0.8*L1 + 0.2*(1-SSIM) ->
 backward.  The optimiser step is outside that span in the reference
-(train.py:126-128) and outside it here.  The default workload is BASELINE.json
-config 3: 1M synthetic Gaussians, 1920x1080, SH degree 3 (see
+(train.py:126-128) and outside it here.  The default workload is the headline
+configuration: 1M synthetic Gaussians, 1920x1080, SH degree 3 (see
 gsplat_host/synthetic.py for the seeded recipe).  With --gpus N (launched by
 torch.distributed.run, one rank per GPU) every rank renders its own view of the
 same replicated cloud (camera rotated by rank*45 degrees) and the scalar loss is
@@ -40,7 +40,7 @@ import torch.distributed as dist  # noqa: E402
 HBM_PEAK_GBS = 8000.0     # MI355X HBM3E spec peak
 
 WORKLOADS = {
-    # name: (P, W, H, sh_degree, skew_fraction)   -- BASELINE.json configs
+    # name: (P, W, H, sh_degree, skew_fraction)
     "c1": (10_000, 256, 256, 0, 0.0),
     "c2": (100_000, 800, 800, 3, 0.0),
     "c3": (1_000_000, 1920, 1080, 3, 0.0),
