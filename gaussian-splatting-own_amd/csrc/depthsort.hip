@@ -69,28 +69,37 @@ __global__ void __launch_bounds__(kThreads) sort_histogram_kernel(const uint32_t
   if (threadIdx.x == 0) s_valid = 0u;
   __syncthreads();
   uint32_t valid = 0;
-  for (size_t i0 = (size_t)blockIdx.x * kThreads; i0 < P; i0 += (size_t)gridDim.x * kThreads) {
-    const size_t i = i0 + threadIdx.x;
-    const uint32_t k = i < P ? keys[i] : kCulled;
-    const bool ok = k != kCulled;
-    valid += ok ? 1u : 0u;
-    // Depth keys are floats: their upper bytes take few distinct values, and 64 lanes adding to one
-    // LDS word serialise.  The first few distinct digits of a wave are counted with a ballot and
-    // added once; what is left (well spread digits) goes through per-lane atomics.
+  constexpr int kPer = 4;   // keys per thread and round, their loads in flight together
+  for (size_t i0 = (size_t)blockIdx.x * (kThreads * kPer); i0 < P; i0 += (size_t)gridDim.x * (kThreads * kPer)) {
+    uint32_t key[kPer];
 #pragma unroll
-    for (int place = 0; place < 4; place++) {
-      const uint32_t d = (k >> (8 * place)) & 255u;
-      unsigned long long rest = __ballot(ok);
+    for (int j = 0; j < kPer; j++) {
+      const size_t i = i0 + (size_t)j * kThreads + threadIdx.x;
+      key[j] = i < P ? keys[i] : kCulled;
+    }
 #pragma unroll
-      for (int it = 0; it < 3; it++) {
-        if (rest == 0ull) break;
-        const int first = __ffsll((long long)rest) - 1;
-        const uint32_t dv = (uint32_t)__shfl((int)d, first);
-        const unsigned long long same = __ballot(ok && d == dv) & rest;
-        if ((int)(threadIdx.x & 63) == first) atomicAdd(&s_h[256 * place + dv], (uint32_t)__popcll(same));
-        rest &= ~same;
+    for (int j = 0; j < kPer; j++) {
+      const uint32_t k = key[j];
+      const bool ok = k != kCulled;
+      valid += ok ? 1u : 0u;
+      // Depth keys are floats: their upper bytes take few distinct values, and 64 lanes adding to
+      // one LDS word serialise.  The first few distinct digits of a wave are counted with a ballot
+      // and added once; what is left (well spread digits) goes through per-lane atomics.
+#pragma unroll
+      for (int place = 0; place < 4; place++) {
+        const uint32_t d = (k >> (8 * place)) & 255u;
+        unsigned long long rest = __ballot(ok);
+#pragma unroll
+        for (int it = 0; it < 3; it++) {
+          if (rest == 0ull) break;
+          const int first = __ffsll((long long)rest) - 1;
+          const uint32_t dv = (uint32_t)__shfl((int)d, first);
+          const unsigned long long same = __ballot(ok && d == dv) & rest;
+          if ((int)(threadIdx.x & 63) == first) atomicAdd(&s_h[256 * place + dv], (uint32_t)__popcll(same));
+          rest &= ~same;
+        }
+        if ((rest >> (threadIdx.x & 63)) & 1ull) atomicAdd(&s_h[256 * place + d], 1u);
       }
-      if ((rest >> (threadIdx.x & 63)) & 1ull) atomicAdd(&s_h[256 * place + d], 1u);
     }
   }
 #pragma unroll
