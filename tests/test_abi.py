@@ -60,3 +60,40 @@ def test_module_surface_matches_the_reference_call_sites():
     assert set(params) == {"means3D", "means2D", "opacities", "shs", "colors_precomp", "scales", "rotations",
                            "cov3D_precomp"}
     assert hasattr(dgr.GaussianRasterizer, "markVisible")
+
+
+def test_scratch_and_size_checks_come_before_any_launch():
+    """Sizes are queried without a GPU; wrong scratch, sizes or totals are refused with a message
+    and no kernel is launched (these calls run on a machine without a GPU)."""
+    lib = ctypes.CDLL(LIB)
+    lib.gsr_last_error.restype = ctypes.c_char_p
+    lib.gsr_bin_sort_bytes.restype = ctypes.c_size_t
+    lib.gsr_bin_lists_bytes.restype = ctypes.c_size_t
+    lib.gsr_totals_words.restype = ctypes.c_size_t
+    vp, sz, u32 = ctypes.c_void_p, ctypes.c_size_t, ctypes.c_uint32
+    lib.gsr_bin_sort.argtypes = [ctypes.c_int, vp, vp, vp, vp, sz, vp]
+    lib.gsr_bin_lists.argtypes = [ctypes.c_int, u32, u32, u32, u32, ctypes.c_int, ctypes.c_int, vp, vp, vp, vp, vp, sz, vp]
+
+    sizes = [lib.gsr_bin_sort_bytes(p) for p in (0, 1, 4096, 4097, 1_000_000, 6_000_000)]
+    assert all(s % 256 == 0 for s in sizes) and sizes == sorted(sizes)
+    assert sizes[4] >= 24 * 1_000_000                      # two key and two value buffers
+    assert lib.gsr_totals_words(0) == 4 and lib.gsr_totals_words(257) == 4 + 4 * 2
+    assert lib.gsr_bin_lists_bytes(0, 0, 0, 1920, 1080) == 256
+    assert lib.gsr_bin_lists_bytes(1000, 1200, 3000, 1920, 1080) % 256 == 0
+
+    fake = vp(0x1000)                                      # never dereferenced: the checks fail first
+    assert lib.gsr_bin_sort(-1, fake, fake, fake, fake, 1 << 20, None) == -1
+    assert lib.gsr_bin_sort(1 << 30, fake, fake, fake, fake, 1 << 20, None) == -1
+    assert lib.gsr_bin_sort(1000, None, fake, fake, fake, 1 << 20, None) == -1 and b"null" in lib.gsr_last_error()
+    rc = lib.gsr_bin_sort(1000, fake, fake, fake, fake, 16, None)
+    assert rc != 0 and b"scratch too small" in lib.gsr_last_error()
+    rc = lib.gsr_bin_sort(1000, fake, fake, fake, vp(0x1010), 1 << 20, None)
+    assert rc != 0 and b"256-byte aligned" in lib.gsr_last_error()
+    assert lib.gsr_bin_sort(0, None, None, None, None, 0, None) == 0          # nothing to do
+
+    rc = lib.gsr_bin_lists(1000, 900, 5000, 800, 3000, 640, 480, fake, fake, fake, None, fake, 1 << 24, None)
+    assert rc == -1 and b"inconsistent totals" in lib.gsr_last_error()      # E1 < V
+    rc = lib.gsr_bin_lists(1000, 900, 5000, 950, 3000, 640, 480, fake, fake, fake, None, fake, 16, None)
+    assert rc != 0 and b"scratch too small" in lib.gsr_last_error()
+    rc = lib.gsr_bin_lists(1000, 900, 5000, 950, 3000, 70000, 480, fake, fake, fake, None, fake, 1 << 24, None)
+    assert rc == -1 and b"too large" in lib.gsr_last_error()
