@@ -34,7 +34,8 @@ def test_debug_mode_gives_the_same_results_and_dumps_on_failure(tmp_path, monkey
         color.square().sum().backward()
         out[debug] = (color.detach().clone(), radii.clone(), xyz.grad.clone())
     assert torch.equal(out[False][0], out[True][0]) and torch.equal(out[False][1], out[True][1])
-    assert torch.allclose(out[False][2], out[True][2], rtol=1e-4, atol=1e-7)
+    # float atomics: the summation order differs from run to run
+    assert float((out[False][2] - out[True][2]).abs().max()) <= 2e-5 * float(out[False][2].abs().max())
 
     # forward failure: SH degree 7 is rejected by the library's argument check
     monkeypatch.chdir(tmp_path)
