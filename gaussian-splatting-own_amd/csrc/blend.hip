@@ -128,15 +128,16 @@ __global__ void __launch_bounds__(256) blend_fwd_kernel(int W, int H, const uint
   const int rounds = (total + kBatch - 1) / kBatch;
 
   // Per-pixel state lives in VGPRs only and the splat body is straight-line, predicated code:
-  // a pixel that is finished (live == 0) or skips a splat simply blends with alpha = 0, which
+  // a pixel that is finished (its threshold is infinite) or skips a splat simply blends with alpha = 0, which
   // leaves T and the colour sums bit for bit unchanged.  Branching per lane instead costs a
   // dozen scalar mask instructions per splat, and the scalar unit is shared by the CU's 4 SIMDs.
-  float live = px.inside ? 1.0f : 0.0f;
+  // the smallest o*G a pixel still accepts: 1/255 while it is live, infinity once it has finished
+  float accept = px.inside ? GSR_ALPHA_MIN : __builtin_inff();
   float T = 1.0f, C0 = 0.f, C1 = 0.f, C2 = 0.f;
   uint32_t last = 0;
 
   for (int b = 0; b < rounds; b++) {
-    const bool wave_done = __ballot(live != 0.0f) == 0ull;
+    const bool wave_done = __ballot(accept < __builtin_inff()) == 0ull;
     if (__syncthreads_and(wave_done)) break;   // also fences the previous batch's LDS reads
 
     // stage one batch
@@ -173,21 +174,21 @@ __global__ void __launch_bounds__(256) blend_fwd_kernel(int W, int H, const uint
           const float p = gauss_exponent(ga.z, ga.w, co.x, dx, dy);
           // alpha = min(.99, oG) is kept iff the exponent is <= 0 and alpha >= 1/255, i.e. oG >= 1/255
           float oG = co.y * __builtin_amdgcn_exp2f(p);
-          const bool keep = (p <= 0.0f) & (oG >= GSR_ALPHA_MIN) & (live != 0.0f);
+          const bool keep = (p <= 0.0f) & (oG >= accept);
           if (__ballot(keep) == 0ull) continue;               // no pixel of the quadrant takes this splat
           oG = keep ? oG : 0.0f;
           const float alpha = __builtin_amdgcn_fmed3f(oG, 0.0f, GSR_ALPHA_MAX);   // min(.99, oG) for oG >= 0
           const float test_T = T * (1.0f - alpha);            // alpha == 0: exactly T
           const bool stop = test_T < GSR_T_STOP;               // implies alpha > 0 (T >= T_STOP while live)
           const float w = stop ? 0.0f : alpha * T;
-          live = stop ? 0.0f : live;
+          accept = stop ? __builtin_inff() : accept;
           T = stop ? T : test_T;
           C0 = fmaf(co.z, w, C0);
           C1 = fmaf(co.w, w, C1);
           C2 = fmaf(blue, w, C2);
           last = (keep & !stop) ? (uint32_t)(b * kBatch + j + 1) : last;   // exactly the pixels with w > 0
         }
-        if (__ballot(live != 0.0f) == 0ull) break;
+        if (__ballot(accept < __builtin_inff()) == 0ull) break;
       }
     }
   }
