@@ -173,20 +173,22 @@ __global__ void __launch_bounds__(256) blend_fwd_kernel(int W, int H, const uint
           const float dx = ga.x - pxf, dy = ga.y - pyf;
           const float p = gauss_exponent(ga.z, ga.w, co.x, dx, dy);
           // alpha = min(.99, oG) is kept iff the exponent is <= 0 and alpha >= 1/255, i.e. oG >= 1/255
-          float oG = co.y * __builtin_amdgcn_exp2f(p);
+          const float oG = co.y * __builtin_amdgcn_exp2f(p);
           const bool keep = (p <= 0.0f) & (oG >= accept);
           if (__ballot(keep) == 0ull) continue;               // no pixel of the quadrant takes this splat
-          oG = keep ? oG : 0.0f;
+          // Pixels that do not take the splat keep computing with whatever their alpha is; every
+          // state update below selects on the decision masks (scalar registers), so none of it lands.
           const float alpha = __builtin_amdgcn_fmed3f(oG, 0.0f, GSR_ALPHA_MAX);   // min(.99, oG) for oG >= 0
-          const float test_T = T * (1.0f - alpha);            // alpha == 0: exactly T
-          const bool stop = test_T < GSR_T_STOP;               // implies alpha > 0 (T >= T_STOP while live)
-          const float w = stop ? 0.0f : alpha * T;
+          const float test_T = T * (1.0f - alpha);
+          const bool stop = keep & (test_T < GSR_T_STOP);      // this splat would take the pixel below 1e-4: it ends here
+          const bool blend = keep & !stop;
+          const float w = blend ? alpha * T : 0.0f;
           accept = stop ? __builtin_inff() : accept;
-          T = stop ? T : test_T;
+          T = blend ? test_T : T;
           C0 = fmaf(co.z, w, C0);
           C1 = fmaf(co.w, w, C1);
           C2 = fmaf(blue, w, C2);
-          last = (keep & !stop) ? (uint32_t)(b * kBatch + j + 1) : last;   // exactly the pixels with w > 0
+          last = blend ? (uint32_t)(b * kBatch + j + 1) : last;
         }
         if (__ballot(accept < __builtin_inff()) == 0ull) break;
       }
