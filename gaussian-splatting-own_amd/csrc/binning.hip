@@ -556,6 +556,17 @@ extern "C" int gsr_bin_sort(int P, const uint32_t* depth_keys, const uint64_t* s
   return gsr::depth_sort(P, depth_keys, sort_vals, sorted_vals, scratch, (hipStream_t)stream);
 }
 
+extern "C" int gsr_bin_sort_status(int P, const void* scratch, size_t scratch_bytes, void* stream) {
+  GSR_REQUIRE(P >= 0 && P < (1 << 30), "bin_sort_status: bad P");
+  if (P == 0) return GSR_OK;
+  GSR_REQUIRE(scratch != nullptr, "bin_sort_status: null pointer");
+  if (scratch_bytes < gsr_bin_sort_bytes(P) || ((uintptr_t)scratch & 255))
+    return gsr::fail(GSR_E_SCRATCH, "bin_sort_status: not the scratch of a sort of %d keys", P);
+  return gsr::depth_sort_status(scratch, (hipStream_t)stream);
+}
+
+extern "C" void gsr_debug_sort_spin_limit(uint32_t limit) { gsr::set_sort_spin_limit(limit); }
+
 extern "C" size_t gsr_bin_lists_bytes(uint32_t V, uint32_t E1, uint32_t E2, int W, int H) {
   if (V == 0 || W <= 0 || H <= 0) return 256;
   return lists_layout(V, E1, E2, make_grid(W, H)).total;

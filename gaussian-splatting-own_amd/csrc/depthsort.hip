@@ -23,6 +23,8 @@
 // Forward progress: a workgroup takes its number from an atomic ticket when it starts running,
 // so every workgroup it waits for is already running or done; the waits are bounded by a spin
 // limit anyway (on overrun the sort sets an error word and still terminates).
+#include <atomic>
+
 #include "gsr_common.h"
 
 namespace {
@@ -40,6 +42,8 @@ constexpr uint32_t kPartial = 1u << 30, kComplete = 2u << 30, kFlags = 3u << 30;
 constexpr int kGroup = 16;                 // workgroups per look-back group
 constexpr int kWindow = 16;                // predecessors inspected per look-back step
 constexpr uint32_t kSpinLimit = 1u << 22;  // look-back steps before giving up (never reached in a healthy run)
+// what the next sorts use; only tests of the give-up path set anything else
+std::atomic<uint32_t> g_spin_limit{kSpinLimit};
 
 // control words behind the 4 x 256 histogram bins
 enum { kCtlValid = 0, kCtlTicket = 1, kCtlError = 5, kCtlWords = 16 };
@@ -121,13 +125,14 @@ struct PassArgs {
   uint32_t* states;       // [workgroup][256] look-back words of this pass
   uint32_t* group_states; // [group][256]
   uint32_t P;
+  uint32_t spin_limit;    // look-back steps before a workgroup gives up and flags the sort as failed
 };
 
 // Sum of the counts published at states[q][t] for q = p, p-1, ..., stop, newest first, waiting
 // for words that are still empty and ending early at a word flagged complete (which already
 // holds everything before it).
-__device__ __forceinline__ uint32_t look_back(const uint32_t* states, int p, int stop, int t, uint32_t* error_word,
-                                              uint32_t error_bit) {
+__device__ __forceinline__ uint32_t look_back(const uint32_t* states, int p, int stop, int t, uint32_t spin_limit,
+                                              uint32_t* error_word, uint32_t error_bit) {
   uint32_t sum = 0, spins = 0;
   while (p >= stop) {
     uint32_t st[kWindow];
@@ -148,7 +153,7 @@ __device__ __forceinline__ uint32_t look_back(const uint32_t* states, int p, int
     }
     if (done) break;
     p -= used;
-    if (++spins > kSpinLimit) { atomicOr(error_word, error_bit); break; }
+    if (++spins > spin_limit) { atomicOr(error_word, error_bit); break; }
   }
   return sum;
 }
@@ -231,7 +236,7 @@ __global__ void __launch_bounds__(kThreads) sort_pass_kernel(PassArgs a) {
     // The workgroup that closes a group collects the group's count right away, ahead of its own
     // ranking: every later group waits for that word.
     if (closes_group) {
-      in_group = look_back(a.states, (int)wg - 1, group * kGroup, tid, &a.ctl[kCtlError], 1u << PASS);
+      in_group = look_back(a.states, (int)wg - 1, group * kGroup, tid, a.spin_limit, &a.ctl[kCtlError], 1u << PASS);
       __hip_atomic_store(group_word, kPartial | (in_group + total), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     }
   }
@@ -282,8 +287,8 @@ __global__ void __launch_bounds__(kThreads) sort_pass_kernel(PassArgs a) {
 
     // look-back: how many items with this digit sit in earlier workgroups
     if (!closes_group)
-      in_group = look_back(a.states, (int)wg - 1, group * kGroup, tid, &a.ctl[kCtlError], 1u << PASS);
-    const uint32_t groups_before = look_back(a.group_states, group - 1, 0, tid, &a.ctl[kCtlError], 16u << PASS);
+      in_group = look_back(a.states, (int)wg - 1, group * kGroup, tid, a.spin_limit, &a.ctl[kCtlError], 1u << PASS);
+    const uint32_t groups_before = look_back(a.group_states, group - 1, 0, tid, a.spin_limit, &a.ctl[kCtlError], 16u << PASS);
     if (closes_group)
       __hip_atomic_store(group_word, kComplete | (groups_before + in_group + total), __ATOMIC_RELAXED,
                          __HIP_MEMORY_SCOPE_AGENT);
@@ -366,10 +371,11 @@ int depth_sort(int P, const uint32_t* keys, const uint64_t* vals, uint64_t* sort
   const unsigned hist_blocks = hist_wanted < 512u ? hist_wanted : 512u;
   hipLaunchKernelGGL(sort_histogram_kernel, dim3(hist_blocks), dim3(kThreads), 0, st, keys, (uint32_t)P, hist, ctl);
   const dim3 grid(L.workgroups), block(kThreads);
+  const uint32_t spin_limit = g_spin_limit.load(std::memory_order_relaxed);
   const size_t per_pass = L.state_words + L.group_words;
   auto args = [&](int pass, const uint32_t* kin, const u64* vin, uint32_t* kout, u64* vout) {
     uint32_t* s = states + pass * per_pass;
-    return PassArgs{kin, vin, kout, vout, hist + 256 * pass, ctl, s, s + L.state_words, (uint32_t)P};
+    return PassArgs{kin, vin, kout, vout, hist + 256 * pass, ctl, s, s + L.state_words, (uint32_t)P, spin_limit};
   };
   if ((uint32_t)P >= kManyFrom) {
     hipLaunchKernelGGL((sort_pass_kernel<0, kManyItems>), grid, block, 0, st, args(0, keys, (const u64*)vals, ka, va));
@@ -384,5 +390,22 @@ int depth_sort(int P, const uint32_t* keys, const uint64_t* vals, uint64_t* sort
   }
   return gsr::check_launch("depth_sort");
 }
+
+// A look-back that ran into its spin limit leaves a bit per pass in the sort's control words (and
+// sorted_vals incomplete: its counts of earlier keys come out too small, so positions stay in range
+// but collide).  The word is read here, after waiting for the stream.
+int depth_sort_status(const void* scratch, hipStream_t st) {
+  const uint32_t* ctl = (const uint32_t*)scratch + kHistWords;
+  uint32_t word = 0;
+  hipError_t e = hipMemcpyAsync(&word, ctl + kCtlError, sizeof(word), hipMemcpyDeviceToHost, st);
+  if (e == hipSuccess) e = hipStreamSynchronize(st);
+  if (e != hipSuccess) return gsr::fail(GSR_E_LAUNCH, "bin_sort_status: %s", hipGetErrorString(e));
+  if (word != 0u)
+    return gsr::fail(GSR_E_SORT, "bin_sort: a look-back gave up waiting (passes 0x%x in groups, 0x%x across groups)",
+                     word & 15u, (word >> 4) & 15u);
+  return GSR_OK;
+}
+
+void set_sort_spin_limit(uint32_t limit) { g_spin_limit.store(limit ? limit : kSpinLimit, std::memory_order_relaxed); }
 
 }  // namespace gsr

@@ -72,6 +72,10 @@ int launch_totals_final(int blocks, const uint32_t* partials, uint32_t* totals, 
 size_t depth_sort_bytes(int P);
 int depth_sort(int P, const uint32_t* keys, const uint64_t* vals, uint64_t* sorted_vals, void* scratch,
                hipStream_t stream);
+// Waits for the stream, then GSR_OK or GSR_E_SORT for the sort that last used this scratch.
+int depth_sort_status(const void* scratch, hipStream_t stream);
+// Look-back steps a workgroup waits before it gives up (0 = the default); for tests of that path.
+void set_sort_spin_limit(uint32_t limit);
 
 }  // namespace gsr
 

@@ -61,6 +61,9 @@ def _load():
     lib.gsr_mark_visible.argtypes = [ci, vp, vp, vp, vp]
     u32 = C.c_uint32
     lib.gsr_bin_sort.argtypes = [ci, vp, vp, vp, vp, C.c_size_t, vp]
+    lib.gsr_bin_sort_status.argtypes = [ci, vp, C.c_size_t, vp]
+    lib.gsr_debug_sort_spin_limit.argtypes = [u32]
+    lib.gsr_debug_sort_spin_limit.restype = None
     lib.gsr_bin_lists.argtypes = [ci, u32, u32, u32, u32, ci, ci, vp, vp, vp, vp, vp, C.c_size_t, vp]
     lib.gsr_blend_fwd.argtypes = [ci, ci, vp, vp, vp, vp, vp, vp, vp, vp]
     lib.gsr_blend_bwd.argtypes = [ci, ci, vp, vp, vp, vp, vp, vp, vp, vp, vp]
@@ -303,6 +306,9 @@ def rasterize_forward(s: GaussianRasterizationSettings, means3D, opacities, shs=
         scratch = torch.empty((nb,), dtype=torch.uint8, device=dev)
         _run("bin_sort", _lib.gsr_bin_sort, P, _ptr(st.depth_keys), _ptr(sort_vals), _ptr(st.sorted_vals),
              _ptr(scratch), nb, stream)
+        if s.debug:
+            # the sort's bounded waits report a failure through a word that only a synchronising call reads
+            _run("bin_sort_status", _lib.gsr_bin_sort_status, P, _ptr(scratch), nb, stream)
         copied.synchronize()
         N, E1, E2, V = (int(v) & 0xFFFFFFFF for v in host.tolist())
     st.num_rendered, st.num_visible = N, V

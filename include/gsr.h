@@ -21,8 +21,8 @@
  *    aligned.
  *  - `stream` is a hipStream_t passed as void* (NULL = the null stream).
  *    Calls only enqueue work; none synchronises.  The one host read-back the
- *    pipeline needs (the list sizes, after gsr_preprocess_geometry) is done by
- *    the caller.
+ *    pipeline needs (the list sizes, after gsr_preprocess_fwd) is done by the
+ *    caller; gsr_bin_sort_status, a check for debugging, is the one exception.
  *  - Return value: 0 = success, negative = error (GSR_E_*); gsr_last_error()
  *    returns a message for the calling thread's last failure.
  *  - Floating tensors are fp32, contiguous.  Layouts follow the reference's
@@ -47,6 +47,7 @@ extern "C" {
 #define GSR_E_INVALID (-1)   /* bad argument (null pointer, negative size, unsupported M/D) */
 #define GSR_E_LAUNCH (-2)    /* HIP reported an error on launch / enqueue                    */
 #define GSR_E_SCRATCH (-3)   /* scratch buffer too small or misaligned                       */
+#define GSR_E_SORT (-4)      /* the depth sort gave up waiting (see gsr_bin_sort_status)     */
 
 /* One 64-byte record per Gaussian, written by gsr_preprocess_fwd and read by
  * the binning and blending kernels: everything a tile needs about a splat in
@@ -149,6 +150,19 @@ int gsr_mark_visible(int P, const float* means3D, const float* viewmatrix, uint8
 size_t gsr_bin_sort_bytes(int P);
 int gsr_bin_sort(int P, const uint32_t* depth_keys, const uint64_t* sort_vals,
                  uint64_t* sorted_vals, void* scratch, size_t scratch_bytes, void* stream);
+
+/* The sort's workgroups wait for each other's digit counts; every wait is
+ * bounded, and a workgroup that runs out of patience flags the sort as failed
+ * instead of hanging (never seen in a healthy run: a workgroup only waits for
+ * workgroups that started before it).  gsr_bin_sort_status WAITS for `stream`,
+ * then returns GSR_OK, or GSR_E_SORT if the sort that last used this scratch
+ * gave up (sorted_vals is then incomplete).  The Python module calls it when
+ * the settings' `debug` flag is set (gaussian_renderer/__init__.py:48), as the
+ * replaced module synchronises and checks for errors in that mode.
+ * gsr_debug_sort_spin_limit sets the patience of later sorts in look-back
+ * steps (0 = default); it exists for tests of this path. */
+int gsr_bin_sort_status(int P, const void* scratch, size_t scratch_bytes, void* stream);
+void gsr_debug_sort_spin_limit(uint32_t limit);
 
 /* gsr_bin_lists: point_list (N) uint32 = Gaussian index per sorted instance;
  * ranges (tiles,2) uint32 = [start,end) into point_list per tile, (0,0) for

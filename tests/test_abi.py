@@ -22,7 +22,8 @@ def declared_symbols():
 def test_header_declares_the_expected_entry_points():
     syms = declared_symbols()
     for s in ("gsr_version", "gsr_last_error", "gsr_preprocess_fwd", "gsr_mark_visible", "gsr_totals_words",
-              "gsr_bin_sort_bytes", "gsr_bin_sort", "gsr_bin_lists_bytes", "gsr_bin_lists", "gsr_blend_fwd", "gsr_blend_bwd",
+              "gsr_bin_sort_bytes", "gsr_bin_sort", "gsr_bin_sort_status", "gsr_debug_sort_spin_limit",
+              "gsr_bin_lists_bytes", "gsr_bin_lists", "gsr_blend_fwd", "gsr_blend_bwd",
               "gsr_preprocess_bwd"):
         assert s in syms
 
@@ -90,6 +91,11 @@ def test_scratch_and_size_checks_come_before_any_launch():
     rc = lib.gsr_bin_sort(1000, fake, fake, fake, vp(0x1010), 1 << 20, None)
     assert rc != 0 and b"256-byte aligned" in lib.gsr_last_error()
     assert lib.gsr_bin_sort(0, None, None, None, None, 0, None) == 0          # nothing to do
+    lib.gsr_bin_sort_status.argtypes = [ctypes.c_int, vp, sz, vp]
+    assert lib.gsr_bin_sort_status(-1, fake, 1 << 20, None) == -1
+    assert lib.gsr_bin_sort_status(1000, None, 1 << 20, None) == -1 and b"null" in lib.gsr_last_error()
+    assert lib.gsr_bin_sort_status(1000, fake, 16, None) == -3
+    assert lib.gsr_bin_sort_status(0, None, 0, None) == 0
 
     rc = lib.gsr_bin_lists(1000, 900, 5000, 800, 3000, 640, 480, fake, fake, fake, None, fake, 1 << 24, None)
     assert rc == -1 and b"inconsistent totals" in lib.gsr_last_error()      # E1 < V

@@ -10,7 +10,8 @@ pytestmark = pytest.mark.gpu
 CULLED = 0xFFFFFFFF
 
 
-def _sort(keys: np.ndarray, vals: np.ndarray) -> np.ndarray:
+def _sort(keys: np.ndarray, vals: np.ndarray, want_status: bool = False):
+    """The sorted values; the status call must report a healthy sort unless the caller wants the code itself."""
     import diff_gaussian_rasterization as dgr
     P = len(keys)
     k = torch.from_numpy(keys.view(np.int32)).cuda()
@@ -20,8 +21,12 @@ def _sort(keys: np.ndarray, vals: np.ndarray) -> np.ndarray:
     scratch = torch.empty((nb,), dtype=torch.uint8, device="cuda")
     dgr._run("bin_sort", dgr._lib.gsr_bin_sort, P, dgr._ptr(k), dgr._ptr(v), dgr._ptr(out), dgr._ptr(scratch), nb,
              dgr._stream())
-    torch.cuda.synchronize()
-    return out.cpu().numpy().view(np.uint64)
+    rc = dgr._lib.gsr_bin_sort_status(P, dgr._ptr(scratch), nb, dgr._stream())     # waits for the stream
+    got = out.cpu().numpy().view(np.uint64)
+    if want_status:
+        return got, rc, dgr._lib.gsr_last_error().decode()
+    assert rc == 0, dgr._lib.gsr_last_error().decode()
+    return got
 
 
 def _check(keys, vals):
@@ -76,3 +81,25 @@ def test_narrow_depth_range_many_groups():
     rng = np.random.default_rng(11)
     P = 16 * 4096 * 3 + 17
     _check(_depth_keys(rng, P, 0.1, lo=5.0, hi=5.5), rng.integers(0, 2**63, P, dtype=np.uint64))
+
+
+def test_a_sort_that_runs_out_of_patience_says_so():
+    """With a patience of one look-back step a workgroup that finds its predecessors' counts missing twice
+    gives up: every kernel still ends, and the status call reports the failure (or, if no workgroup
+    happened to wait, a complete sort).  The default patience is back afterwards."""
+    import diff_gaussian_rasterization as dgr
+    rng = np.random.default_rng(13)
+    P = 1_000_000
+    keys, vals = _depth_keys(rng, P, 0.1), rng.integers(0, 2**63, P, dtype=np.uint64)
+    order = np.argsort(keys, kind="stable")
+    order = order[keys[order] != CULLED]
+    dgr._lib.gsr_debug_sort_spin_limit(1)
+    try:
+        got, rc, message = _sort(keys, vals, want_status=True)
+    finally:
+        dgr._lib.gsr_debug_sort_spin_limit(0)
+    if rc == 0:
+        assert np.array_equal(got[:len(order)], vals[order])
+    else:
+        assert rc == -4 and "gave up" in message
+    _check(keys, vals)
