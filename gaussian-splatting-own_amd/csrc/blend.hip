@@ -108,6 +108,21 @@ __device__ __forceinline__ void stage_record(Staged* slot, const uint4 r0, const
   *reinterpret_cast<float2*>(&slot->blue) = make_float2(__uint_as_float(r2.z), __uint_as_float(id));
 }
 
+// The backward's slot: the same ten words without the padding, 40 bytes, read and written 8 bytes at a
+// time (a 16-byte access wants 16-byte alignment).  The 2 KB saved per workgroup are what lets a CU
+// hold eight workgroups of the backward instead of seven.
+struct __align__(8) StagedBack {
+  float2 xy, lab, lco, rg, bi;   // (x, y) (la, lb) (lc, opacity) (r, g) (blue, index bits)
+};
+
+__device__ __forceinline__ void stage_record(StagedBack* slot, const uint4 r0, const uint4 r1, const uint4 r2, uint32_t id) {
+  slot->xy = make_float2(__uint_as_float(r0.x), __uint_as_float(r0.y));
+  slot->lab = make_float2(-0.5f * kLog2e * __uint_as_float(r1.x), -kLog2e * __uint_as_float(r1.y));
+  slot->lco = make_float2(-0.5f * kLog2e * __uint_as_float(r1.z), __uint_as_float(r1.w));
+  slot->rg = make_float2(__uint_as_float(r2.x), __uint_as_float(r2.y));
+  slot->bi = make_float2(__uint_as_float(r2.z), __uint_as_float(id));
+}
+
 // ---------------------------------------------------------------------------
 // forward
 // ---------------------------------------------------------------------------
@@ -208,10 +223,12 @@ __global__ void __launch_bounds__(256) blend_fwd_kernel(int W, int H, const uint
 // ---------------------------------------------------------------------------
 // backward
 // ---------------------------------------------------------------------------
-// Dwords per row of the backward's reduction scratch: 64 lane values + 32.  With this stride the
-// 16-byte reads of blend_bwd_kernel (lane 8k+s reads dwords 4s..4s+3 and 32+4s..32+4s+3 of row k)
-// touch 64 distinct banks in each of ds_read_b128's four groups of 16 lanes.
-constexpr int kRedStride = 96;
+// The backward's reduction scratch holds 8 rows of 64 lane values per wave.  Odd rows are stored
+// rotated by 32 words: the 16-byte reads of blend_bwd_kernel (lane 8k+s reads words 4s..4s+3 and
+// 32+4s..32+4s+3 of row k) then touch 64 distinct banks in each of ds_read_b128's four groups of 16
+// lanes (rows 2m and 2m+1 would otherwise meet in the same 32 banks) without any padding between
+// the rows, and LDS is what limits how many workgroups a CU holds.
+constexpr int kRedStride = 64;
 
 template <int CTRL>
 __device__ __forceinline__ float dpp_add(float v) {
@@ -238,7 +255,7 @@ __global__ void __launch_bounds__(256) blend_bwd_kernel(int W, int H, const uint
                                                         const uint32_t* __restrict__ n_contrib,
                                                         const float* __restrict__ dL_dpix,
                                                         float* __restrict__ dL_dsplat) {
-  __shared__ Staged s_splat[kBatch];
+  __shared__ StagedBack s_splat[kBatch];
   __shared__ unsigned long long s_mask[4][4];
   __shared__ int s_last[4];
   __shared__ __align__(16) float s_red[4][8 * kRedStride];   // per wave: 8 rows of 64 lane values
@@ -269,7 +286,12 @@ __global__ void __launch_bounds__(256) blend_bwd_kernel(int W, int H, const uint
   // acc = colour composited behind the current splat (everything already visited in this
   // back-to-front walk), per channel.
   float T = Tf, acc0 = 0.f, acc1 = 0.f, acc2 = 0.f;
-  float* red = s_red[wave];
+  // where this lane writes its value of an even / odd row, and where it reads its two quarters of row lane/8
+  float* const red_even = s_red[wave] + lane;
+  float* const red_odd = s_red[wave] + ((lane + 32) & 63);
+  const int my_row = lane >> 3, my_rot = 32 * (my_row & 1), my_seg = 4 * (lane & 7);
+  const float4* const red_lo = reinterpret_cast<const float4*>(s_red[wave] + my_row * kRedStride + ((my_seg + my_rot) & 63));
+  const float4* const red_hi = reinterpret_cast<const float4*>(s_red[wave] + my_row * kRedStride + ((my_seg + 32 + my_rot) & 63));
 
   for (int b = (tile_last - 1) / kBatch; b >= 0; b--) {
     __syncthreads();
@@ -303,16 +325,14 @@ __global__ void __launch_bounds__(256) blend_bwd_kernel(int W, int H, const uint
         m &= ~(1ull << bit);
         const int j = sw * 64 + bit;
         const int pos = b * kBatch + j;   // 0-based position in the tile list
-        const Staged* sp = &s_splat[j];
-        const float4 ga = sp->geo;
-        const float4 co = sp->col;
-        const float blue = sp->blue;
-        const float dx = ga.x - pxf, dy = ga.y - pyf;
+        const StagedBack* sp = &s_splat[j];
+        const float2 xy = sp->xy, lab = sp->lab, lco = sp->lco;
+        const float dx = xy.x - pxf, dy = xy.y - pyf;
         // same alpha and same keep / skip decision as the forward (min(.99, oG) >= 1/255 exactly when
         // oG >= 1/255), as straight-line code: a pixel that did not blend this splat gets oG = 0,
         // hence alpha = 0, which leaves T and acc unchanged below and zeroes its contributions
-        const float p = gauss_exponent(ga.z, ga.w, co.x, dx, dy);
-        float oG = co.y * __builtin_amdgcn_exp2f(p);
+        const float p = gauss_exponent(lab.x, lab.y, lco.x, dx, dy);
+        float oG = lco.y * __builtin_amdgcn_exp2f(p);
         const bool hit = (p <= 0.0f) & (oG >= GSR_ALPHA_MIN) & (pos < last);
         if (__ballot(hit) == 0ull) continue;
         oG = hit ? oG : 0.0f;
@@ -321,7 +341,8 @@ __global__ void __launch_bounds__(256) blend_bwd_kernel(int W, int H, const uint
         const float inv = __builtin_amdgcn_rcpf(1.0f - alpha);     // alpha == 0: exactly 1
         T = T * inv;                                               // transmittance in front of the splat
         const float dch = alpha * T;
-        const float d0 = co.z - acc0, d1 = co.w - acc1, d2 = blue - acc2;
+        const float2 rg = sp->rg, bi = sp->bi;
+        const float d0 = rg.x - acc0, d1 = rg.y - acc1, d2 = bi.x - acc2;
         const float dL_dalpha = (d0 * dp0 + d1 * dp1 + d2 * dp2) * T - (Tf * inv) * bg_dot;
         acc0 = fmaf(alpha, d0, acc0);                              // alpha c + (1 - alpha) acc
         acc1 = fmaf(alpha, d1, acc1);
@@ -335,20 +356,19 @@ __global__ void __launch_bounds__(256) blend_bwd_kernel(int W, int H, const uint
         // way to do this on gfx950 (36 of them cost as much as the rest of the loop), so the sums
         // are transposed through LDS instead: every lane stores its nine values as columns
         // (conflict-free), then lane 8k+s adds up eight elements of row k, fetched with two 16-byte
-        // reads (conflict-free for the row stride chosen above), and three DPP steps combine the
+        // reads (conflict-free for the row layout chosen above), and three DPP steps combine the
         // eight lanes of a row.  The ninth sum stays in registers: four DPP steps within the rows of
         // 16 lanes, two lane-permute swaps across them.  A wave's LDS operations execute in order, so
         // no barrier is needed.
-        red[0 * kRedStride + lane] = u;
-        red[1 * kRedStride + lane] = ux;
-        red[2 * kRedStride + lane] = uy;
-        red[3 * kRedStride + lane] = ux * dx;
-        red[4 * kRedStride + lane] = ux * dy;
-        red[5 * kRedStride + lane] = uy * dy;
-        red[6 * kRedStride + lane] = dch * dp0;
-        red[7 * kRedStride + lane] = dch * dp1;
-        const float4* rp = reinterpret_cast<const float4*>(red + (lane >> 3) * kRedStride) + (lane & 7);
-        const float4 a0 = rp[0], a1 = rp[8];
+        red_even[0 * kRedStride] = u;
+        red_odd[1 * kRedStride] = ux;
+        red_even[2 * kRedStride] = uy;
+        red_odd[3 * kRedStride] = ux * dx;
+        red_even[4 * kRedStride] = ux * dy;
+        red_odd[5 * kRedStride] = uy * dy;
+        red_even[6 * kRedStride] = dch * dp0;
+        red_odd[7 * kRedStride] = dch * dp1;
+        const float4 a0 = *red_lo, a1 = *red_hi;
         float v = ((a0.x + a0.y) + (a0.z + a0.w)) + ((a1.x + a1.y) + (a1.z + a1.w));
         float v8 = dch * dp2;
         v = dpp_add<0xB1>(v); v = dpp_add<0x4E>(v); v = dpp_add<0x141>(v);       // over the 8 segment lanes
@@ -358,7 +378,7 @@ __global__ void __launch_bounds__(256) blend_bwd_kernel(int W, int H, const uint
         // wave-instruction on nine consecutive dwords of one 64-byte row = one atomic request
         const bool ninth = lane == 1;
         if ((lane & 7) == 0 || ninth)
-          atomicAdd(dL_dsplat + (size_t)sp->id * GSR_GRAD_WORDS + (ninth ? 8 : (lane >> 3)), ninth ? v8 : v);
+          atomicAdd(dL_dsplat + (size_t)__float_as_uint(bi.y) * GSR_GRAD_WORDS + (ninth ? 8 : (lane >> 3)), ninth ? v8 : v);
       }
     }
   }
