@@ -324,6 +324,110 @@ __global__ void __launch_bounds__(Level<1>::kThreads) count1_kernel(LevelArgs a)
     a.counts[blockIdx.x + f * np] = (uint32_t)s_d[(f / FX) * stride + f % FX];
 }
 
+// Level 1 writing without a sweep over the buckets, for grids of at most 64 supercells.  Every entry
+// turns its rectangle of supercells into a 64-bit coverage mask (bit f = covers supercell f).  The
+// masks of 64 consecutive entries form a 64 x 64 bit matrix held one row per lane; its transpose,
+// six exchange steps between lanes, leaves in lane f the word "which of the 64 entries cover
+// supercell f" -- the ballot the sweep computes once per bucket, for all buckets at once.  The
+// popcounts of those words, prefix-summed over the piece's steps of 64 entries on top of the piece's
+// positions from the scan, give every (step, supercell) its first output slot; an entry's rank
+// within its step is the number of lower lanes in the supercell's word.  Each entry then walks
+// over the bits of its own mask (one or two supercells for most; the wave loops as long as its
+// widest entry).
+__device__ __forceinline__ u64 shfl_xor64(u64 v, int lanes) {
+  const uint32_t lo = (uint32_t)__shfl_xor((int)(uint32_t)v, lanes), hi = (uint32_t)__shfl_xor((int)(uint32_t)(v >> 32), lanes);
+  return ((u64)hi << 32) | lo;
+}
+
+__device__ __forceinline__ u64 transpose_bits64(u64 x, int lane) {
+  constexpr u64 kLow[6] = {0x00000000ffffffffull, 0x0000ffff0000ffffull, 0x00ff00ff00ff00ffull,
+                           0x0f0f0f0f0f0f0f0full, 0x3333333333333333ull, 0x5555555555555555ull};
+#pragma unroll
+  for (int k = 0; k < 6; k++) {
+    const int s = 32 >> k;
+    const u64 y = shfl_xor64(x, s);
+    // blocks of s x s bits: the lane without bit s keeps its low blocks and takes the partner's low
+    // blocks as its high ones, the lane with bit s the other way round
+    x = (lane & s) ? (((y & ~kLow[k]) >> s) | (x & ~kLow[k])) : ((x & kLow[k]) | ((y & kLow[k]) << s));
+  }
+  return x;
+}
+
+constexpr int kSteps1 = (int)(kPiece1 / 64);                       // steps of 64 entries per piece
+static_assert(kPiece1 == 2 * Level<1>::kThreads && kSteps1 <= 64, "write1_kernel: two entries per thread, steps scanned by one wave");
+
+__global__ void __launch_bounds__(Level<1>::kThreads) write1_kernel(LevelArgs a) {
+  constexpr uint32_t L = Level<1>::kPiece;
+  constexpr int kWaves = Level<1>::kThreads / 64;
+  __shared__ uint32_t s_base[kSteps1][65];     // [step][supercell]: counts, then first output slots; 65: the scan reads columns
+  const uint32_t np = (a.V + L - 1) / L;
+  if (blockIdx.x >= np) return;
+  const uint32_t start = blockIdx.x * L, len = min(L, a.V - start);
+  const uint32_t F = (uint32_t)a.g.supercells(), FX = (uint32_t)a.g.sx;
+  const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+
+  // the piece's positions of this wave's supercells (used after the first barrier)
+  constexpr int kPerWave = 64 / kWaves;
+  uint32_t piece_pos = 0;
+  if (lane < kPerWave && (uint32_t)(wave * kPerWave + lane) < F)
+    piece_pos = a.counts[blockIdx.x + (uint32_t)(wave * kPerWave + lane) * np];
+
+  u64 en[2], mask[2], cover[2];
+#pragma unroll
+  for (int k = 0; k < 2; k++) {
+    const uint32_t i = (uint32_t)((wave * 2 + k) * 64 + lane);
+    en[k] = i < len ? a.in[start + i] : 0ull;
+  }
+#pragma unroll
+  for (int k = 0; k < 2; k++) {
+    const int step = wave * 2 + k;
+    const uint32_t i = (uint32_t)(step * 64 + lane);
+    u64 m = 0ull;
+    if (i < len) {
+      uint32_t x0, x1, y0, y1;
+      a.pk.rect(en[k], x0, x1, y0, y1);
+      const uint32_t bx0 = x0 / kSuper, bx1 = x1 / kSuper, by0 = y0 / kSuper, by1 = y1 / kSuper;
+      const u64 row = ((2ull << (bx1 - bx0)) - 1ull) << bx0;       // a width of 64 wraps to all ones
+      for (uint32_t y = by0; y <= by1; y++) m |= row << (y * FX);
+    }
+    mask[k] = m;
+    cover[k] = transpose_bits64(m, lane);                         // lane = supercell
+    s_base[step][lane] = (uint32_t)__popcll(cover[k]);
+  }
+  __syncthreads();
+
+  // exclusive prefix sum over the steps, per supercell: lane = step, kPerWave supercells per wave
+#pragma unroll
+  for (int q = 0; q < kPerWave; q++) {
+    const int f = wave * kPerWave + q;
+    const uint32_t c = lane < kSteps1 ? s_base[lane][f] : 0u;
+    uint32_t inc = c;
+#pragma unroll
+    for (int o = 1; o < kSteps1; o <<= 1) {
+      const uint32_t u = __shfl_up(inc, o);
+      if (lane >= o) inc += u;
+    }
+    const uint32_t first = (uint32_t)__shfl((int)piece_pos, q);
+    if (lane < kSteps1) s_base[lane][f] = first + inc - c;
+  }
+  __syncthreads();
+
+#pragma unroll
+  for (int k = 0; k < 2; k++) {
+    const int step = wave * 2 + k;
+    u64 m = mask[k];
+    const uint32_t cover_lo = (uint32_t)cover[k], cover_hi = (uint32_t)(cover[k] >> 32);
+    while (__ballot(m != 0ull) != 0ull) {
+      // every lane takes part in the exchange; the ones with nothing left fetch supercell 0's word and write nothing
+      const int f = m ? __ffsll((long long)m) - 1 : 0;
+      const uint32_t lo = (uint32_t)__shfl((int)cover_lo, f), hi = (uint32_t)__shfl((int)cover_hi, f);
+      const uint32_t rank = __builtin_amdgcn_mbcnt_hi(hi, __builtin_amdgcn_mbcnt_lo(lo, 0u));
+      if (m) a.out64[s_base[step][f] + rank] = en[k];
+      m &= m - 1ull;
+    }
+  }
+}
+
 // ---------------------------------------------------------------------------
 // prefix sums between the sweeps: one block each
 // ---------------------------------------------------------------------------
@@ -609,7 +713,10 @@ extern "C" int gsr_bin_lists(int P, uint32_t V, uint32_t N, uint32_t E1, uint32_
     hipLaunchKernelGGL((partition_kernel<1, false>), dim3(L.pieces1), dim3(Level<1>::kThreads), 0, st, a);
   hipLaunchKernelGGL(scan1_kernel, dim3(1), dim3(kScanBlock), 0, st, g, V, a.counts, (uint32_t*)(base + L.list_start2),
                      (uint32_t*)(base + L.list_len2), (uint32_t*)(base + L.piece_first2), (uint4*)(base + L.desc2));
-  hipLaunchKernelGGL((partition_kernel<1, true>), dim3(L.pieces1), dim3(Level<1>::kThreads), 0, st, a);
+  if (g.supercells() <= 64)
+    hipLaunchKernelGGL(write1_kernel, dim3(L.pieces1), dim3(Level<1>::kThreads), 0, st, a);
+  else
+    hipLaunchKernelGGL((partition_kernel<1, true>), dim3(L.pieces1), dim3(Level<1>::kThreads), 0, st, a);
   int rc = gsr::check_launch("bin_lists: level 1");
   if (rc) return rc;
 
