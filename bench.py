@@ -17,13 +17,20 @@ Rank 0 prints ONE JSON line.  `value` is render throughput, Msplats/s = Gaussian
 submitted per second of forward render (preprocess + binning + blend), summed
 over ranks, measured with device events inside the timed training steps;
 `ms_per_step` is the whole train step.  `roofline` prices the dominant
-hand-written kernel against HBM with the ALGORITHMIC bytes of one launch;
-`cpu_baseline` times the C oracle's forward render of the same workload on the
-host cores (rank 0, N=1 only).
+hand-written kernel against HBM with the ALGORITHMIC bytes of one launch over
+the kernel's own duration (events stamped by the launch itself, not brackets on
+the stream), and says from committed counter runs which of HBM, vector issue and
+LDS is closest to its limit; `cpu_baseline` times the C oracle's forward render
+of the same workload on the host cores (rank 0, N=1 only).  On the default
+workload at one GPU the line also carries, as `variants`, the same step through
+the reference's unchanged operator API (PyTorch activations feeding
+GaussianRasterizer) and on the no-early-termination scene (every opacity 0.1,
+the reference's initial value, scene/gaussian_model.py:139).
 """
 from __future__ import annotations
 
 import argparse
+import glob
 import json
 import math
 import os
@@ -38,15 +45,18 @@ import torch  # noqa: E402
 import torch.distributed as dist  # noqa: E402
 
 HBM_PEAK_GBS = 8000.0     # MI355X HBM3E spec peak
+CLOCK_HZ = 2.4e9          # peak shader clock; the chip may hold less under load, so the busy fractions below are lower bounds
+SIMDS, CUS = 1024, 256
 
 WORKLOADS = {
-    # name: (P, W, H, sh_degree, skew_fraction)
-    "c1": (10_000, 256, 256, 0, 0.0),
-    "c2": (100_000, 800, 800, 3, 0.0),
-    "c3": (1_000_000, 1920, 1080, 3, 0.0),
-    "c5": (6_000_000, 1920, 1080, 3, 0.5),
+    # name: (P, W, H, sh_degree, skew_fraction, opacity_const)
+    "c1": (10_000, 256, 256, 0, 0.0, None),
+    "c2": (100_000, 800, 800, 3, 0.0, None),
+    "c3": (1_000_000, 1920, 1080, 3, 0.0, None),
+    # the C3 cloud with every opacity 0.1: no pixel saturates early, every tile list is walked far deeper
+    "c3w": (1_000_000, 1920, 1080, 3, 0.0, 0.1),
+    "c5": (6_000_000, 1920, 1080, 3, 0.5, None),
 }
-
 
 DOMINANT_STAGE = "blend_bwd"      # the longest kernel of the step on every workload here
 
@@ -78,27 +88,138 @@ def published_binning_bytes(P, V, N, W, H):
     return 8 * P + 12 * N + 8 * V + 24 * N * math.ceil(key_bits / 8) + 8 * N + 8 * tiles
 
 
-def measured_traffic(workload):
-    """HBM bytes per launch from the committed rocprofv3 counter runs (FETCH_SIZE / WRITE_SIZE
-    passes, corrected as profiles/r01_traffic.json says), or {} when none exists for this workload."""
-    path = os.path.join(ROOT, "profiles", "r01_traffic.json")
-    try:
-        with open(path) as f:
-            t = json.load(f)
-        return t["bytes_per_launch"] if t.get("workload") == workload else {}
-    except (OSError, ValueError, KeyError):
-        return {}
+def committed_counters(workload):
+    """(file name, contents) of the newest committed counter summary for this workload
+    (profiles/rNN_traffic*.json, written by tools/make_traffic_json.py from rocprofv3 --pmc runs), or (None, {})."""
+    for path in sorted(glob.glob(os.path.join(ROOT, "profiles", "r*_traffic*.json")), reverse=True):
+        try:
+            with open(path) as f:
+                t = json.load(f)
+        except (OSError, ValueError):
+            continue
+        if t.get("workload") == workload:
+            return os.path.relpath(path, ROOT), t
+    return None, {}
 
 
-def measured_valu(workload):
-    """Vector-ALU counters per launch from the same committed counter runs, or {}."""
-    path = os.path.join(ROOT, "profiles", "r01_traffic.json")
-    try:
-        with open(path) as f:
-            t = json.load(f)
-        return t.get("valu", {}) if t.get("workload") == workload else {}
-    except (OSError, ValueError):
-        return {}
+def limits(kernel, ms, alg_bytes, counters, source):
+    """How close one kernel runs to each of its three candidate limits, from its duration and the committed
+    counters of the same workload.  hbm: measured HBM bytes over the 8 TB/s peak.  valu: vector
+    wave-instructions x 2 issue cycles (a wave64 instruction occupies a SIMD-32 for two cycles) over the
+    cycles of the 1024 SIMDs.  lds: cycles the LDS pipes were busy issuing (SQ_ACTIVE_INST_LDS, which counts
+    quad-cycles) over the cycles of the 256 CUs' LDS units.  The last two assume the 2.4 GHz peak clock."""
+    t = ms * 1e-3
+    out = {"algorithmic_bytes": alg_bytes, "source": source}
+    traffic = counters.get("bytes_per_launch", {}).get(kernel)
+    fr = {"hbm_algorithmic": alg_bytes / t / (HBM_PEAK_GBS * 1e9)}
+    if traffic:
+        out["measured_hbm_bytes"] = traffic
+        fr["hbm_measured"] = traffic / t / (HBM_PEAK_GBS * 1e9)
+    valu = counters.get("valu", {}).get(kernel)
+    if valu:
+        out["valu_wave_instructions"] = valu["wave_instructions"]
+        fr["valu_issue"] = 2.0 * valu["wave_instructions"] / (SIMDS * t * CLOCK_HZ)
+    lds = counters.get("lds", {}).get(kernel)
+    if lds:
+        out["lds_wave_instructions"] = lds.get("wave_instructions")
+        out["lds_bank_conflict_cycles"] = lds.get("bank_conflict_cycles")
+        if lds.get("active_quad_cycles"):
+            fr["lds_issue"] = 4.0 * lds["active_quad_cycles"] / (CUS * t * CLOCK_HZ)
+    out["fractions_of_peak"] = {k: round(v, 3) for k, v in fr.items()}
+    real = {k: v for k, v in fr.items() if k != "hbm_algorithmic"}
+    if real:
+        top = max(real, key=real.get)
+        out["limited_by"] = {"hbm_measured": "HBM bandwidth", "valu_issue": "vector-instruction issue",
+                             "lds_issue": "the LDS pipe"}[top] + f" ({real[top]:.0%} of its peak; the others: " + \
+            ", ".join(f"{k} {v:.0%}" for k, v in real.items() if k != top) + ")"
+    return out
+
+
+class Scene:
+    def __init__(self, workload, dev, rank):
+        from gsplat_host.cameras import orbit_camera
+        from gsplat_host.model import GaussianParams
+        from gsplat_host.synthetic import make_cloud
+        self.name = workload
+        self.P, self.W, self.H, self.deg, skew, opacity = WORKLOADS[workload]
+        self.cloud = make_cloud(self.P, sh_degree=self.deg, seed=0, skew_fraction=skew, opacity_const=opacity)
+        self.model = GaussianParams(self.cloud, max_sh_degree=3 if self.deg == 3 else self.deg, device=dev)
+        self.cam = orbit_camera(self.W, self.H, angle_deg=45.0 * rank, device=dev)
+        self.bg = torch.zeros(3, device=dev)                                   # train.py:41
+        self.gt = torch.rand(3, self.H, self.W, generator=torch.Generator().manual_seed(1)).to(dev)
+        self.params = [p for p in self.model.parameters()]
+
+
+def measure(scene, dgr, fused, steps, warmup, use_dist=False, dp_grads=False, opt=None, stage_table=True):
+    """`steps` timed train steps of one scene: wall time over all of them (between barriers), the forward
+    render by device events inside them, the two blend kernels by the launch's own events; then, untimed,
+    one more pass with every stage bracketed for the per-stage table."""
+    from gsplat_host.loss import photometric_loss
+    from gsplat_host.optim import all_reduce_gradients
+    from gsplat_host.render import PipelineParams, render
+    pipe = PipelineParams(fused_activations=fused)
+    timer = dgr.StageTimer(only=(), exact=dgr.StageTimer.EXACT_STAGES)
+    all_stages = dgr.StageTimer()
+    fwd_events = []
+    state = {"pending": None, "grad_scale": 1.0, "out": None}
+
+    def step(timed):
+        for p in scene.params:
+            p.grad = None
+        if timed:
+            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            e0.record()
+        out = render(scene.cam, scene.model, pipe, scene.bg)
+        if timed:
+            e1.record()
+            fwd_events.append((e0, e1))
+        loss = photometric_loss(out["render"], scene.gt)
+        loss.backward()
+        if use_dist:
+            # RCCL over xGMI: one fp32 scalar.  Nothing in the next step needs the mean loss, so the
+            # collective runs on RCCL's own stream beside it; the previous one is waited for first, so
+            # at most one is outstanding, and the last one before the closing barrier.
+            if state["pending"] is not None:
+                state["pending"][0].wait()
+            lv = loss.detach().clone()
+            state["pending"] = (dist.all_reduce(lv, async_op=True), lv)
+        if dp_grads:
+            state["grad_scale"] = all_reduce_gradients(opt.params)        # RCCL over xGMI: 59 floats per Gaussian
+        state["out"] = out
+
+    def barrier():
+        if state["pending"] is not None:
+            state["pending"][0].wait()
+            state["pending"] = None
+        torch.cuda.synchronize()
+        if use_dist:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    for _ in range(warmup):
+        step(False)
+    barrier()
+    dgr.set_stage_timer(timer)
+    t0 = time.perf_counter()
+    for _ in range(steps):
+        step(True)
+    barrier()
+    elapsed = time.perf_counter() - t0
+    dgr.set_stage_timer(None)
+    exact = timer.exact_ms()
+    timer.close()
+    stage_ms = {}
+    if stage_table:
+        dgr.set_stage_timer(all_stages)
+        for _ in range(steps):
+            step(False)
+        barrier()
+        dgr.set_stage_timer(None)
+        stage_ms = all_stages.mean_ms()
+    render_ms = sum(a.elapsed_time(b) for a, b in fwd_events) / len(fwd_events)
+    radii = state["out"]["radii"]
+    return {"elapsed": elapsed, "render_ms": render_ms, "exact": exact, "stage_ms": stage_ms,
+            "visible": int((radii > 0).sum().item()), "grad_scale": state["grad_scale"]}
 
 
 def main():
@@ -108,6 +229,8 @@ def main():
     ap.add_argument("--warmup", type=int, default=5)
     ap.add_argument("--workload", default="c3", choices=sorted(WORKLOADS))
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-variants", action="store_true",
+                    help="skip the extra measurements of the default line (reference operator API, opacity-0.1 scene)")
     ap.add_argument("--unfused", action="store_true",
                     help="apply the model's activations with PyTorch ops, as the reference does, instead of in-kernel")
     ap.add_argument("--short-lists", action="store_true",
@@ -135,90 +258,18 @@ def main():
     import diff_gaussian_rasterization as dgr
     if args.short_lists:
         dgr.REFERENCE_LISTS = False
-    from gsplat_host.cameras import orbit_camera
-    from gsplat_host.loss import photometric_loss
-    from gsplat_host.model import GaussianParams
-    from gsplat_host.render import PipelineParams, render
-    from gsplat_host.synthetic import make_cloud
+    from gsplat_host.optim import GaussianAdam
 
-    P, W, H, deg, skew = WORKLOADS[args.workload]
-    cloud = make_cloud(P, sh_degree=deg, seed=0, skew_fraction=skew)
-    model = GaussianParams(cloud, max_sh_degree=3 if deg == 3 else deg, device=dev)
-    cam = orbit_camera(W, H, angle_deg=45.0 * rank, device=dev)
-    bg = torch.zeros(3, device=dev)                                   # train.py:41
-    gt = torch.rand(3, H, W, generator=torch.Generator().manual_seed(1)).to(dev)
-    pipe = PipelineParams(fused_activations=not args.unfused)
-    params = [p for p in model.parameters()]
+    scene = Scene(args.workload, dev, rank)
+    P, W, H, deg = scene.P, scene.W, scene.H, scene.deg
+    opt = GaussianAdam.for_model(scene.model)
+    m = measure(scene, dgr, not args.unfused, args.steps, args.warmup, use_dist, args.dp_grads, opt)
 
-    from gsplat_host.optim import GaussianAdam, all_reduce_gradients
-    opt = GaussianAdam.for_model(model)
-
-    # Inside the timed steps only the dominant kernel is bracketed by events (every bracket costs
-    # the step a few microseconds of device idle time: all eight stages together ~0.09 ms of a
-    # 1.06 ms step); the per-stage table comes from a second, untimed pass.
-    timer = dgr.StageTimer(only=(DOMINANT_STAGE,))
-    all_stages = dgr.StageTimer()
-    fwd_events = []
-
-    def step(timed: bool):
-        for p in params:
-            p.grad = None
-        if timed:
-            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-            e0.record()
-        out = render(cam, model, pipe, bg)
-        if timed:
-            e1.record()
-            fwd_events.append((e0, e1))
-        loss = photometric_loss(out["render"], gt)
-        loss.backward()
-        if use_dist:
-            # RCCL over xGMI: one fp32 scalar.  Nothing in the next step needs the mean loss, so the
-            # collective runs on RCCL's own stream beside it; the previous one is waited for first, so
-            # at most one is outstanding, and the last one before the closing barrier.
-            if step.pending is not None:
-                step.pending[0].wait()
-            lv = loss.detach().clone()
-            step.pending = (dist.all_reduce(lv, async_op=True), lv)
-        if args.dp_grads:
-            step.grad_scale = all_reduce_gradients(opt.params)        # RCCL over xGMI: 59 floats per Gaussian
-        return out
-    step.grad_scale = 1.0
-    step.pending = None
-
-    def barrier():
-        if step.pending is not None:
-            step.pending[0].wait()
-            step.pending = None
-        torch.cuda.synchronize()
-        if use_dist:
-            dist.barrier()
-        torch.cuda.synchronize()
-
-    for _ in range(args.warmup):
-        step(False)
-    barrier()
-    dgr.set_stage_timer(timer)
-    t0 = time.perf_counter()
-    for _ in range(args.steps):
-        out = step(True)
-    barrier()
-    elapsed = time.perf_counter() - t0
-    dgr.set_stage_timer(all_stages)
-    for _ in range(args.steps):
-        step(False)
-    barrier()
-    dgr.set_stage_timer(None)
-
+    elapsed, render_ms = m["elapsed"], m["render_ms"]
     if use_dist:
-        t = torch.tensor([elapsed], device=dev, dtype=torch.float64)
+        t = torch.tensor([elapsed, render_ms], device=dev, dtype=torch.float64)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
-        elapsed = float(t.item())
-    render_ms = sum(a.elapsed_time(b) for a, b in fwd_events) / len(fwd_events)
-    if use_dist:
-        t = torch.tensor([render_ms], device=dev, dtype=torch.float64)
-        dist.all_reduce(t, op=dist.ReduceOp.MAX)
-        render_ms = float(t.item())
+        elapsed, render_ms = float(t[0].item()), float(t[1].item())
     ms_per_step = 1e3 * elapsed / args.steps
     msplats = world * P / (render_ms * 1e-3) / 1e6
 
@@ -228,38 +279,38 @@ def main():
     for _ in range(5):
         e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
         e0.record()
-        opt.step(grad_scale=step.grad_scale)
+        opt.step(grad_scale=m["grad_scale"])
         e1.record()
         adam_events.append((e0, e1))
     torch.cuda.synchronize()
     adam_ms = sorted(a.elapsed_time(b) for a, b in adam_events)[len(adam_events) // 2]
-    n_params = sum(p.numel() for p in params)
+    n_params = sum(p.numel() for p in scene.params)
 
     if rank == 0:
-        stage_ms = all_stages.mean_ms()
-        stage_ms.update(timer.mean_ms())          # the dominant kernel: as measured inside the timed steps
-        N = int((out["radii"] > 0).sum().item())
-        st_N = _instances(dgr, cam, model, bg)
+        stage_ms = dict(m["stage_ms"])
+        for k, (mean, lo, hi, n) in m["exact"].items():
+            stage_ms[k] = mean                     # the blend kernels: the kernel's own duration inside the timed steps
+        N = m["visible"]
+        st_N = _instances(dgr, scene)
         alg = algorithmic_bytes(P, st_N, W, H)
         dominant = max(alg, key=lambda k: stage_ms.get(k, 0.0))
         if dominant != DOMINANT_STAGE:
-            print(f"warning: {dominant} outlasts {DOMINANT_STAGE}; its time comes from the untimed pass", file=sys.stderr)
-        achieved = alg[dominant] / (stage_ms[dominant] * 1e-3) / 1e9
+            print(f"warning: {dominant} outlasts {DOMINANT_STAGE}", file=sys.stderr)
+        dom_ms = stage_ms[dominant]
+        achieved = alg[dominant] / (dom_ms * 1e-3) / 1e9
         kernels = {k: {"ms": round(stage_ms[k], 4), "algorithmic_GB": round(alg[k] / 1e9, 4) if k in alg else None,
                        "GBps": round(alg[k] / (stage_ms[k] * 1e-3) / 1e9, 1) if k in alg else None}
                    for k in stage_ms}
-        bin_ms = sum(stage_ms.get(k, 0.0) for k in ("bin_totals", "bin_sort", "bin_lists"))
+        for k, (mean, lo, hi, n) in m["exact"].items():
+            kernels[k].update({"timing": "kernel start to end, stamped by the launch", "min_ms": round(lo, 4),
+                               "max_ms": round(hi, 4), "launches": n})
+        bin_ms = sum(stage_ms.get(k, 0.0) for k in ("bin_sort", "bin_lists"))
         pub = published_binning_bytes(P, N, st_N, W, H)
-        kernels["binning_total"] = {"ms": round(bin_ms, 4), "published_chain_GB": round(pub / 1e9, 4),
-                                    "GBps_vs_published_chain": round(pub / (bin_ms * 1e-3) / 1e9, 1)}
-        traffic = measured_traffic(args.workload).get(dominant)
-        valu = measured_valu(args.workload).get(dominant)
-        valu_note = None
-        if valu:
-            # SQ_ACTIVE_INST_VALU counts quad-cycles over all 1024 SIMDs (256 CUs x 4)
-            busy = 4.0 * valu["active_quad_cycles"] / 1024.0 / (stage_ms[dominant] * 1e-3 * 2.4e9)
-            valu_note = {"wave_instructions": valu["wave_instructions"], "busy_frac_at_2.4GHz": round(busy, 3),
-                         "source": "profiles/r01_traffic.json (rocprofv3 SQ_INSTS_VALU, SQ_ACTIVE_INST_VALU)"}
+        if bin_ms > 0:
+            kernels["binning_total"] = {"ms": round(bin_ms, 4), "published_chain_GB": round(pub / 1e9, 4),
+                                        "GBps_vs_published_chain": round(pub / (bin_ms * 1e-3) / 1e9, 1)}
+        source, counters = committed_counters(args.workload)
+        lim = limits(dominant, dom_ms, alg[dominant], counters, source)
         line = {
             "metric": "train-step ms + render Msplats/s @1080p, 1M Gaussians, 1/2/4/8 MI355X",
             "value": round(msplats, 2), "unit": "Msplats/s", "n_gpus": world, "steps": args.steps,
@@ -273,11 +324,13 @@ def main():
             "train_step_ms": round(ms_per_step, 3), "render_ms": round(render_ms, 3),
             "render_Ginstances_per_s": round(world * st_N / (render_ms * 1e-3) / 1e9, 2),
             "roofline": {"bound": "hbm", "kernel": dominant, "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS,
-                         "unit": "GB/s", "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": traffic,
-                         "traffic_unit": "bytes/launch (rocprofv3 FETCH_SIZE x2 + WRITE_SIZE, profiles/r01_traffic.json)",
-                         "algorithmic_bytes": alg[dominant], "valu": valu_note,
-                         "limited_by": "vector-instruction issue (VALU), not HBM" if valu_note and
-                                       valu_note["busy_frac_at_2.4GHz"] > 0.8 else None},
+                         "unit": "GB/s", "frac": round(achieved / HBM_PEAK_GBS, 4),
+                         "traffic": lim.get("measured_hbm_bytes"),
+                         "traffic_unit": "bytes/launch (rocprofv3 FETCH_SIZE x2 + WRITE_SIZE)",
+                         "kernel_ms": round(dom_ms, 4),
+                         "kernel_ms_from": "HIP events stamped by the kernel's launch (its own start and end), mean "
+                                           f"over the {args.steps} timed steps",
+                         **lim},
             "kernels": kernels,
             "optimizer": {"what": "fused Adam over the six parameter tensors, outside the timed step as in the reference",
                           "ms": round(adam_ms, 4), "parameters": n_params,
@@ -285,20 +338,54 @@ def main():
             "gradient_exchange": "all-reduce of all gradients inside the timed step" if args.dp_grads
                                  else "none (scalar loss only)",
         }
+        if world == 1 and args.workload == "c3" and not args.no_variants and not args.unfused:
+            line["variants"] = variants(scene, dgr, args, dev)
         if world == 1 and not args.no_cpu_baseline:
-            line["cpu_baseline"] = cpu_baseline(cloud, W, H, deg)
+            line["cpu_baseline"] = cpu_baseline(scene.cloud, W, H, deg)
         print(json.dumps(line), flush=True)
     if use_dist:
         dist.barrier()
         dist.destroy_process_group()
 
 
-def _instances(dgr, cam, model, bg):
+def variants(scene, dgr, args, dev):
+    """The default workload's step measured two more ways, shorter runs of the same loop:
+    through the reference's unchanged operator API (its model getters as PyTorch ops feeding
+    GaussianRasterizer, gaussian_renderer/__init__.py:53-93), and on the same cloud with every opacity
+    0.1 (the reference's initial opacity): nothing saturates early, the hard case for the blend kernels."""
+    out = {}
+    steps, warmup = max(5, args.steps // 2), 3
+    m = measure(scene, dgr, False, steps, warmup, stage_table=False)
+    out["reference_operator_api"] = {
+        "what": "activations as PyTorch ops (exp, sigmoid, normalize, cat) feeding GaussianRasterizer, as the reference calls it",
+        "render_ms": round(m["render_ms"], 3), "train_step_ms": round(1e3 * m["elapsed"] / steps, 3),
+        "render_Msplats_per_s": round(scene.P / (m["render_ms"] * 1e-3) / 1e6, 1), "steps": steps}
+    hard = Scene("c3w", dev, 0)
+    m = measure(hard, dgr, True, steps, warmup, stage_table=True)
+    n_inst = _instances(dgr, hard)
+    alg = algorithmic_bytes(hard.P, n_inst, hard.W, hard.H)
+    bwd_ms, fwd_ms = m["exact"]["blend_bwd"][0], m["exact"]["blend_fwd"][0]
+    source, counters = committed_counters("c3w")
+    out["c3w_opacity_0.1"] = {
+        "what": "the same cloud with every opacity 0.1 (scene/gaussian_model.py:139): no early termination",
+        "render_ms": round(m["render_ms"], 3), "train_step_ms": round(1e3 * m["elapsed"] / steps, 3),
+        "render_Msplats_per_s": round(hard.P / (m["render_ms"] * 1e-3) / 1e6, 1), "steps": steps,
+        "tile_instances": n_inst, "stage_ms": {k: round(v, 4) for k, v in m["stage_ms"].items()},
+        "blend_fwd": {"kernel_ms": round(fwd_ms, 4), "algorithmic_GBps": round(alg["blend_fwd"] / fwd_ms / 1e6, 1),
+                      "frac_of_hbm_peak": round(alg["blend_fwd"] / fwd_ms / 1e6 / HBM_PEAK_GBS, 4)},
+        "blend_bwd": {"kernel_ms": round(bwd_ms, 4), "algorithmic_GBps": round(alg["blend_bwd"] / bwd_ms / 1e6, 1),
+                      "frac_of_hbm_peak": round(alg["blend_bwd"] / bwd_ms / 1e6 / HBM_PEAK_GBS, 4),
+                      **limits("blend_bwd", bwd_ms, alg["blend_bwd"], counters, source)}}
+    return out
+
+
+def _instances(dgr, scene):
     """Number of (tile, splat) instances of the benchmarked view (untimed)."""
+    cam, model = scene.cam, scene.model
     with torch.no_grad():
         s = dgr.GaussianRasterizationSettings(
             image_height=cam.image_height, image_width=cam.image_width, tanfovx=math.tan(cam.FoVx * 0.5),
-            tanfovy=math.tan(cam.FoVy * 0.5), bg=bg, scale_modifier=1.0, viewmatrix=cam.world_view_transform,
+            tanfovy=math.tan(cam.FoVy * 0.5), bg=scene.bg, scale_modifier=1.0, viewmatrix=cam.world_view_transform,
             projmatrix=cam.full_proj_transform, sh_degree=model.active_sh_degree, campos=cam.camera_center,
             prefiltered=False, debug=False)
         st = dgr.rasterize_forward(s, model.get_xyz, model.get_opacity, shs=model.get_features,
@@ -309,8 +396,9 @@ def _instances(dgr, cam, model, bg):
 
 
 def cpu_baseline(cloud, W, H, deg):
-    """Forward render of the same workload by the C oracle (a port: the
-    reference has no CPU rasterizer), on the host cores, timed once."""
+    """Forward render of the same workload by the C oracle, on the host cores.  A PORT: the reference has
+    no CPU rasterizer (its only implementation is the CUDA one), so this is the build's own C / OpenMP
+    restatement of the algorithm, not PyTorch-CPU; its depth sort runs on one core."""
     import numpy as np
     import oracle
     from gsplat_host.cameras import orbit_camera
@@ -331,8 +419,9 @@ def cpu_baseline(cloud, W, H, deg):
         reps += 1
     dt = (time.perf_counter() - t0) / reps
     return {"value": round(cloud.count / dt / 1e6, 4), "unit": "Msplats/s", "cores": threads, "kind": "port",
-            "sample": f"{reps} forward renders (preprocess + binning + blend) of the full workload, {dt:.2f} s each; "
-                      "blend and preprocess run on all cores (OpenMP), the sort on one"}
+            "sample": f"{reps} forward renders (preprocess + binning + blend) of the full workload, {dt:.2f} s each, by "
+                      "the C/OpenMP oracle (not PyTorch-CPU: the reference has no CPU rasterizer); blend and "
+                      "preprocess run on all cores, the sort on one"}
 
 
 if __name__ == "__main__":

@@ -76,7 +76,9 @@ __device__ __forceinline__ uint32_t wave_sum(uint32_t v) {
 }
 
 // Sums the per-block partial records the preprocess geometry kernel leaves behind.
+// totals[4] = the caller's status word as it stands (0 without one): it rides to the host with the sizes.
 __global__ void __launch_bounds__(kScanBlock) totals_final_kernel(int blocks, const uint32_t* __restrict__ partials,
+                                                                  const uint32_t* __restrict__ status,
                                                                   uint32_t* __restrict__ totals) {
   __shared__ uint32_t s_part[kScanBlock / 64][4];
   uint32_t acc[4] = {0u, 0u, 0u, 0u};
@@ -104,6 +106,7 @@ __global__ void __launch_bounds__(kScanBlock) totals_final_kernel(int blocks, co
     for (int w = 0; w < kScanBlock / 64; w++) t += s_part[w][threadIdx.x];
     totals[threadIdx.x] = t;
   }
+  if (threadIdx.x == 4) totals[4] = status ? *status : 0u;
 }
 
 // ---------------------------------------------------------------------------
@@ -114,9 +117,27 @@ __global__ void __launch_bounds__(kScanBlock) totals_final_kernel(int blocks, co
 // exclusive prefix sum over the whole array, which is ordered (parent, bucket, piece),
 // turns every count into the absolute output position of that piece's first entry for
 // that bucket.
+// What the host believed when it sized the buffers, against what the device knows.  The list sizes
+// (N, E1, E2, V) travel to the host and back as plain numbers, and the depth sort may have given up:
+// a builder that ran on other numbers than the preprocess produced, or on an incomplete sort, would
+// write past its buffers.  The three level-1 kernels check; a refusing scan1_kernel leaves no level-2
+// pieces behind, which empties every later kernel of the chain, and all tile ranges come out (0,0).
+struct Guard {
+  const uint32_t* sort_error;   // non-zero = the depth sort that produced the input gave up (may be null)
+  const uint32_t* totals;       // (N, E1, E2, V) as the preprocess left them on the device (may be null)
+  uint32_t N, E1, E2, V;        // the host's copy
+  __device__ __forceinline__ uint32_t refusal() const {
+    uint32_t r = 0u;
+    if (sort_error && *sort_error != 0u) r |= GSR_STATUS_SORT;
+    if (totals && (totals[0] != N || totals[1] != E1 || totals[2] != E2 || totals[3] != V)) r |= GSR_STATUS_TOTALS;
+    return r;
+  }
+};
+
 struct LevelArgs {
   Grid g;
   Pack pk;
+  Guard guard;
   uint32_t V;                          // level 1: number of visible Gaussians
   const u64* in;                       // level 1: packed (index, rectangle) words front to back;
                                        // level 2: the same words per supercell list;
@@ -156,7 +177,7 @@ __global__ void __launch_bounds__(Level<LEVEL>::kThreads) partition_kernel(Level
   uint32_t parent = 0, start, len, np, slot0, F, FX;
   if (LEVEL == 1) {
     np = (a.V + L - 1) / L;
-    if (blockIdx.x >= np) return;
+    if (blockIdx.x >= np || a.guard.refusal()) return;
     start = blockIdx.x * L;
     len = min(L, a.V - start);
     slot0 = blockIdx.x;
@@ -286,7 +307,7 @@ __global__ void __launch_bounds__(Level<1>::kThreads) count1_kernel(LevelArgs a)
   constexpr int kIter = (int)L / T;
   __shared__ int s_d[kMaxDiffCells];
   const uint32_t np = (a.V + L - 1) / L;
-  if (blockIdx.x >= np) return;
+  if (blockIdx.x >= np || a.guard.refusal()) return;
   const uint32_t start = blockIdx.x * L, len = min(L, a.V - start);
   const uint32_t FX = (uint32_t)a.g.sx, FY = (uint32_t)a.g.sy, stride = FX + 1u, rows = FY + 1u;
   for (uint32_t i = threadIdx.x; i < stride * rows; i += T) s_d[i] = 0;
@@ -361,7 +382,7 @@ __global__ void __launch_bounds__(Level<1>::kThreads) write1_kernel(LevelArgs a)
   constexpr int kWaves = Level<1>::kThreads / 64;
   __shared__ uint32_t s_base[kSteps1][65];     // [step][supercell]: counts, then first output slots; 65: the scan reads columns
   const uint32_t np = (a.V + L - 1) / L;
-  if (blockIdx.x >= np) return;
+  if (blockIdx.x >= np || a.guard.refusal()) return;
   const uint32_t start = blockIdx.x * L, len = min(L, a.V - start);
   const uint32_t F = (uint32_t)a.g.supercells(), FX = (uint32_t)a.g.sx;
   const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
@@ -523,11 +544,19 @@ __device__ void build_pieces(uint32_t n, const uint32_t* list_start, const uint3
 }
 
 // After the level-1 counting sweep: positions, the supercell lists, the level-2 pieces.
-__global__ void __launch_bounds__(kScanBlock) scan1_kernel(Grid g, uint32_t V, uint32_t* counts, uint32_t* list_start,
+__global__ void __launch_bounds__(kScanBlock) scan1_kernel(Grid g, Guard guard, uint32_t* status, uint32_t V,
+                                                           uint32_t* counts, uint32_t* list_start,
                                                            uint32_t* list_len, uint32_t* piece_first, uint4* desc) {
   __shared__ uint32_t s_wave[kScanBlock / 64];
   __shared__ uint32_t s_first[kFirstLds];
   const uint32_t F = (uint32_t)g.supercells(), np = (V + kPiece1 - 1) / kPiece1, slots = np * F;
+  const uint32_t refused = guard.refusal();
+  if (refused) {
+    // no level-2 pieces: every later kernel of the chain finds nothing to do, all tile ranges become (0,0)
+    for (uint32_t b = threadIdx.x; b <= F; b += kScanBlock) piece_first[b] = 0u;
+    if (threadIdx.x == 0 && status) atomicOr(status, refused);
+    return;
+  }
   const uint32_t total = block_scan_inplace(counts, slots, s_wave);
   __syncthreads();
   for (uint32_t b = threadIdx.x; b < F; b += kScanBlock) {
@@ -642,8 +671,9 @@ ListsLayout lists_layout(uint32_t V, uint32_t E1, uint32_t E2, const Grid& g) {
 
 }  // namespace
 
-int gsr::launch_totals_final(int blocks, const uint32_t* partials, uint32_t* totals, hipStream_t stream) {
-  hipLaunchKernelGGL(totals_final_kernel, dim3(1), dim3(kScanBlock), 0, stream, blocks, partials, totals);
+int gsr::launch_totals_final(int blocks, const uint32_t* partials, const uint32_t* status, uint32_t* totals,
+                             hipStream_t stream) {
+  hipLaunchKernelGGL(totals_final_kernel, dim3(1), dim3(kScanBlock), 0, stream, blocks, partials, status, totals);
   return gsr::check_launch("totals");
 }
 
@@ -676,9 +706,14 @@ extern "C" size_t gsr_bin_lists_bytes(uint32_t V, uint32_t E1, uint32_t E2, int 
   return lists_layout(V, E1, E2, make_grid(W, H)).total;
 }
 
+extern "C" const uint32_t* gsr_bin_sort_error_word(const void* sort_scratch) {
+  return sort_scratch ? gsr::depth_sort_error_word(sort_scratch) : nullptr;
+}
+
 extern "C" int gsr_bin_lists(int P, uint32_t V, uint32_t N, uint32_t E1, uint32_t E2, int W, int H,
                              const uint64_t* sorted_vals, uint32_t* point_list, uint32_t* ranges,
-                             uint32_t* tile_ids_sorted, void* scratch, size_t scratch_bytes, void* stream) {
+                             uint32_t* tile_ids_sorted, const uint32_t* sort_error, const uint32_t* totals,
+                             uint32_t* status, void* scratch, size_t scratch_bytes, void* stream) {
   GSR_REQUIRE(P >= 0 && W > 0 && H > 0, "bin_lists: bad sizes");
   GSR_REQUIRE(ranges, "bin_lists: null ranges");
   hipStream_t st = (hipStream_t)stream;
@@ -702,6 +737,7 @@ extern "C" int gsr_bin_lists(int P, uint32_t V, uint32_t N, uint32_t E1, uint32_
   a.pk = gsr::make_pack(P, g.gx, g.gy);
   GSR_REQUIRE(a.pk.bits() <= 64, "bin_lists: sizes do not fit the 64-bit sort value");
   a.V = V;
+  a.guard = Guard{sort_error, totals, N, E1, E2, V};
 
   // level 1: depth-sorted Gaussians -> supercell lists
   a.in = (const u64*)sorted_vals;
@@ -711,7 +747,7 @@ extern "C" int gsr_bin_lists(int P, uint32_t V, uint32_t N, uint32_t E1, uint32_
     hipLaunchKernelGGL(count1_kernel, dim3(L.pieces1), dim3(Level<1>::kThreads), 0, st, a);
   else
     hipLaunchKernelGGL((partition_kernel<1, false>), dim3(L.pieces1), dim3(Level<1>::kThreads), 0, st, a);
-  hipLaunchKernelGGL(scan1_kernel, dim3(1), dim3(kScanBlock), 0, st, g, V, a.counts, (uint32_t*)(base + L.list_start2),
+  hipLaunchKernelGGL(scan1_kernel, dim3(1), dim3(kScanBlock), 0, st, g, a.guard, status, V, a.counts, (uint32_t*)(base + L.list_start2),
                      (uint32_t*)(base + L.list_len2), (uint32_t*)(base + L.piece_first2), (uint4*)(base + L.desc2));
   if (g.supercells() <= 64)
     hipLaunchKernelGGL(write1_kernel, dim3(L.pieces1), dim3(Level<1>::kThreads), 0, st, a);

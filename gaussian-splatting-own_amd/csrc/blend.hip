@@ -10,6 +10,8 @@
 // set bits of its own masks — scalar bit iteration, order preserved — and reads
 // the splat with LDS broadcast loads.  Splats that cannot reach any pixel of a
 // quadrant cost that wave nothing.
+#include <hip/hip_ext.h>
+
 #include "gsr_common.h"
 
 namespace {
@@ -386,24 +388,67 @@ __global__ void __launch_bounds__(256) blend_bwd_kernel(int W, int H, const uint
 
 }  // namespace
 
-extern "C" int gsr_blend_fwd(int W, int H, const uint32_t* ranges, const uint32_t* point_list,
-                             const uint32_t* records, const float* bg, float* out_color, float* final_T,
-                             uint32_t* n_contrib, void* stream) {
+namespace {
+
+// With events the launch goes through hipExtLaunchKernelGGL, which stamps them with the kernel's own
+// start and end (what a profiler's kernel trace reports), instead of with the stream's progress around it.
+int launch_blend_fwd(int W, int H, const uint32_t* ranges, const uint32_t* point_list, const uint32_t* records,
+                     const float* bg, float* out_color, float* final_T, uint32_t* n_contrib, hipEvent_t start,
+                     hipEvent_t stop, void* stream) {
   GSR_REQUIRE(W > 0 && H > 0, "blend_fwd: bad image size %dx%d", W, H);
   GSR_REQUIRE(ranges && bg && out_color && final_T && n_contrib, "blend_fwd: null pointer");
   dim3 grid(gsr::div_up(W, GSR_TILE_X), gsr::div_up(H, GSR_TILE_Y)), block(256);
-  hipLaunchKernelGGL(blend_fwd_kernel, grid, block, 0, (hipStream_t)stream, W, H, (const uint2*)ranges, point_list,
-                     (const uint4*)records, bg, out_color, final_T, n_contrib);
+  if (start || stop)
+    hipExtLaunchKernelGGL(blend_fwd_kernel, grid, block, 0, (hipStream_t)stream, start, stop, 0, W, H, (const uint2*)ranges,
+                          point_list, (const uint4*)records, bg, out_color, final_T, n_contrib);
+  else
+    hipLaunchKernelGGL(blend_fwd_kernel, grid, block, 0, (hipStream_t)stream, W, H, (const uint2*)ranges, point_list,
+                       (const uint4*)records, bg, out_color, final_T, n_contrib);
   return gsr::check_launch("blend_fwd");
+}
+
+int launch_blend_bwd(int W, int H, const uint32_t* ranges, const uint32_t* point_list, const uint32_t* records,
+                     const float* bg, const float* final_T, const uint32_t* n_contrib, const float* dL_dpix,
+                     float* dL_dsplat, hipEvent_t start, hipEvent_t stop, void* stream) {
+  GSR_REQUIRE(W > 0 && H > 0, "blend_bwd: bad image size %dx%d", W, H);
+  GSR_REQUIRE(ranges && bg && final_T && n_contrib && dL_dpix && dL_dsplat, "blend_bwd: null pointer");
+  GSR_REQUIRE(((uintptr_t)dL_dsplat & 63) == 0, "blend_bwd: dL_dsplat must be 64-byte aligned");
+  dim3 grid(gsr::div_up(W, GSR_TILE_X), gsr::div_up(H, GSR_TILE_Y)), block(256);
+  if (start || stop)
+    hipExtLaunchKernelGGL(blend_bwd_kernel, grid, block, 0, (hipStream_t)stream, start, stop, 0, W, H, (const uint2*)ranges,
+                          point_list, (const uint4*)records, bg, final_T, n_contrib, dL_dpix, dL_dsplat);
+  else
+    hipLaunchKernelGGL(blend_bwd_kernel, grid, block, 0, (hipStream_t)stream, W, H, (const uint2*)ranges, point_list,
+                       (const uint4*)records, bg, final_T, n_contrib, dL_dpix, dL_dsplat);
+  return gsr::check_launch("blend_bwd");
+}
+
+}  // namespace
+
+extern "C" int gsr_blend_fwd(int W, int H, const uint32_t* ranges, const uint32_t* point_list,
+                             const uint32_t* records, const float* bg, float* out_color, float* final_T,
+                             uint32_t* n_contrib, void* stream) {
+  return launch_blend_fwd(W, H, ranges, point_list, records, bg, out_color, final_T, n_contrib, nullptr, nullptr, stream);
 }
 
 extern "C" int gsr_blend_bwd(int W, int H, const uint32_t* ranges, const uint32_t* point_list,
                              const uint32_t* records, const float* bg, const float* final_T,
                              const uint32_t* n_contrib, const float* dL_dpix, float* dL_dsplat, void* stream) {
-  GSR_REQUIRE(W > 0 && H > 0, "blend_bwd: bad image size %dx%d", W, H);
-  GSR_REQUIRE(ranges && bg && final_T && n_contrib && dL_dpix && dL_dsplat, "blend_bwd: null pointer");
-  dim3 grid(gsr::div_up(W, GSR_TILE_X), gsr::div_up(H, GSR_TILE_Y)), block(256);
-  hipLaunchKernelGGL(blend_bwd_kernel, grid, block, 0, (hipStream_t)stream, W, H, (const uint2*)ranges, point_list,
-                     (const uint4*)records, bg, final_T, n_contrib, dL_dpix, dL_dsplat);
-  return gsr::check_launch("blend_bwd");
+  return launch_blend_bwd(W, H, ranges, point_list, records, bg, final_T, n_contrib, dL_dpix, dL_dsplat, nullptr, nullptr,
+                          stream);
+}
+
+extern "C" int gsr_blend_fwd_timed(int W, int H, const uint32_t* ranges, const uint32_t* point_list,
+                                   const uint32_t* records, const float* bg, float* out_color, float* final_T,
+                                   uint32_t* n_contrib, void* start_event, void* stop_event, void* stream) {
+  return launch_blend_fwd(W, H, ranges, point_list, records, bg, out_color, final_T, n_contrib, (hipEvent_t)start_event,
+                          (hipEvent_t)stop_event, stream);
+}
+
+extern "C" int gsr_blend_bwd_timed(int W, int H, const uint32_t* ranges, const uint32_t* point_list,
+                                   const uint32_t* records, const float* bg, const float* final_T,
+                                   const uint32_t* n_contrib, const float* dL_dpix, float* dL_dsplat,
+                                   void* start_event, void* stop_event, void* stream) {
+  return launch_blend_bwd(W, H, ranges, point_list, records, bg, final_T, n_contrib, dL_dpix, dL_dsplat,
+                          (hipEvent_t)start_event, (hipEvent_t)stop_event, stream);
 }

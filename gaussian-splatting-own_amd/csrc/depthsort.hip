@@ -182,6 +182,11 @@ __global__ void __launch_bounds__(kThreads) sort_pass_kernel(PassArgs a) {
   constexpr int kShift = 8 * PASS;
   const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
 
+  // A pass that follows one in which a look-back gave up would rank keys that were never written
+  // against the up-front histograms, and its positions would no longer be bounded by the key count:
+  // the failure is sticky, every later pass of the sort does nothing (one scalar load, uniform).
+  if (PASS > 0 && a.ctl[kCtlError] != 0u) return;
+
   if (tid == 0) s_misc[0] = atomicAdd(&a.ctl[kCtlTicket + PASS], 1u);
   if (tid < 256) s_total[tid] = 0u;
 #pragma unroll
@@ -317,8 +322,10 @@ __global__ void __launch_bounds__(kThreads) sort_pass_kernel(PassArgs a) {
     if (r < mine_n) {
       const uint32_t kk = s_keys[r];
       const uint32_t dst = s_dest[(kk >> kShift) & 255u] + r;
-      if (PASS < 3) a.keys_out[dst] = kk;
-      a.vals_out[dst] = s_vals[r];
+      if (dst < a.P) {     // always true in a healthy sort; holds the stores inside the buffers whatever a failed look-back returned
+        if (PASS < 3) a.keys_out[dst] = kk;
+        a.vals_out[dst] = s_vals[r];
+      }
     }
   }
   STAMP(6);
@@ -391,9 +398,11 @@ int depth_sort(int P, const uint32_t* keys, const uint64_t* vals, uint64_t* sort
   return gsr::check_launch("depth_sort");
 }
 
-// A look-back that ran into its spin limit leaves a bit per pass in the sort's control words (and
-// sorted_vals incomplete: its counts of earlier keys come out too small, so positions stay in range
-// but collide).  The word is read here, after waiting for the stream.
+// A look-back that ran into its spin limit leaves a bit per pass in the sort's control words.  In that
+// pass the counts of earlier keys come out too small, so its positions collide (still below the key
+// count); the passes after it see the word and do nothing, and every store is bounded by P: nothing
+// outside the sort's buffers is written, but sorted_vals is incomplete.  The word is read here, after
+// waiting for the stream; gsr_bin_lists reads it on the device (gsr_bin_sort_error_word).
 int depth_sort_status(const void* scratch, hipStream_t st) {
   const uint32_t* ctl = (const uint32_t*)scratch + kHistWords;
   uint32_t word = 0;
@@ -405,6 +414,8 @@ int depth_sort_status(const void* scratch, hipStream_t st) {
                      word & 15u, (word >> 4) & 15u);
   return GSR_OK;
 }
+
+const uint32_t* depth_sort_error_word(const void* scratch) { return (const uint32_t*)scratch + kHistWords + kCtlError; }
 
 void set_sort_spin_limit(uint32_t limit) { g_spin_limit.store(limit ? limit : kSpinLimit, std::memory_order_relaxed); }
 

@@ -62,9 +62,10 @@ inline Pack make_pack(int P, int tiles_x, int tiles_y) {
   return k;
 }
 
-// Sums `blocks` partial records of four counters (partials[4 * b + k]) into totals[0..3];
-// defined with the binning kernels.
-int launch_totals_final(int blocks, const uint32_t* partials, uint32_t* totals, hipStream_t stream);
+// Sums `blocks` partial records of four counters (partials[4 * b + k]) into totals[0..3] and copies
+// the caller's status word (null = 0) to totals[4]; defined with the binning kernels.
+int launch_totals_final(int blocks, const uint32_t* partials, const uint32_t* status, uint32_t* totals,
+                        hipStream_t stream);
 
 // Depth sort of the binning (defined in depthsort.hip): sorted_vals[0 .. visible) = the values whose
 // key is not 0xFFFFFFFF, by ascending key, equal keys in input order.  scratch: depth_sort_bytes(P)
@@ -74,6 +75,8 @@ int depth_sort(int P, const uint32_t* keys, const uint64_t* vals, uint64_t* sort
                hipStream_t stream);
 // Waits for the stream, then GSR_OK or GSR_E_SORT for the sort that last used this scratch.
 int depth_sort_status(const void* scratch, hipStream_t stream);
+// Device address of the word that is non-zero after a sort that gave up (inside its scratch).
+const uint32_t* depth_sort_error_word(const void* scratch);
 // Look-back steps a workgroup waits before it gives up (0 = the default); for tests of that path.
 void set_sort_spin_limit(uint32_t limit);
 

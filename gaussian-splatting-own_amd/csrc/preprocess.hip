@@ -427,7 +427,7 @@ __global__ void __launch_bounds__(kBlock, 4) preprocess_bwd_kernel(BwdArgs a) {
     g0.z = -0.5f * m0.w;
     g0.w = -m1.x;
     g1.x = -0.5f * m1.y;
-    g1.y = m0.x / op;
+    g1.y = op > 0.0f ? m0.x / op : 0.0f;   // opacity 0 blends nowhere: sum u is 0 and so is the gradient, not 0/0
     g1.z = m1.z;
     g1.w = m1.w;
   }
@@ -660,15 +660,16 @@ __global__ void __launch_bounds__(kBlock, 4) preprocess_bwd_kernel(BwdArgs a) {
 
 }  // namespace
 
-extern "C" size_t gsr_totals_words(int P) { return 4 + 4 * (size_t)(P > 0 ? gsr::div_up(P, kBlock) : 0); }
+constexpr int kTotalsHead = 8;   // N, E1, E2, V, status, 3 spare words; the per-block partial sums follow
+extern "C" size_t gsr_totals_words(int P) { return kTotalsHead + 4 * (size_t)(P > 0 ? gsr::div_up(P, kBlock) : 0); }
 
 namespace {
 
-int launch_preprocess_fwd(const char* who, FwdArgs a, int D, uint32_t* totals, void* stream) {
+int launch_preprocess_fwd(const char* who, FwdArgs a, int D, uint32_t* totals, const uint32_t* status, void* stream) {
   hipStream_t st = (hipStream_t)stream;
   const int blocks = gsr::div_up(a.P, kBlock);
   dim3 grid(blocks), block(kBlock);
-  a.partials = totals + 4;
+  a.partials = totals + kTotalsHead;
   switch (a.shs ? D : 0) {
     case 0: hipLaunchKernelGGL(preprocess_fwd_kernel<0>, grid, block, 0, st, a); break;
     case 1: hipLaunchKernelGGL(preprocess_fwd_kernel<1>, grid, block, 0, st, a); break;
@@ -677,7 +678,7 @@ int launch_preprocess_fwd(const char* who, FwdArgs a, int D, uint32_t* totals, v
   }
   int rc = gsr::check_launch(who);
   if (rc) return rc;
-  return gsr::launch_totals_final(blocks, totals + 4, totals, st);
+  return gsr::launch_totals_final(blocks, totals + kTotalsHead, status, totals, st);
 }
 
 }  // namespace
@@ -689,11 +690,11 @@ extern "C" int gsr_preprocess_fwd(int P, int D, int M, const float* means3D, con
                                   int W, int H, float tanfovx, float tanfovy, int prefiltered, int reference_lists,
                                   uint32_t* records, int32_t* radii, uint32_t* tiles_touched,
                                   uint32_t* depth_keys, uint32_t* rects, uint64_t* sort_vals, uint32_t* totals,
-                                  uint8_t* visible, void* stream) {
+                                  const uint32_t* status, uint8_t* visible, void* stream) {
   (void)prefiltered;
   GSR_REQUIRE(P >= 0 && W > 0 && H > 0, "preprocess_fwd: bad sizes P=%d W=%d H=%d", P, W, H);
   GSR_REQUIRE(totals && ((uintptr_t)totals & 15) == 0, "preprocess_fwd: totals must be non-null and 16-byte aligned");
-  if (P == 0) return gsr::launch_totals_final(0, totals + 4, totals, (hipStream_t)stream);
+  if (P == 0) return gsr::launch_totals_final(0, totals + kTotalsHead, status, totals, (hipStream_t)stream);
   GSR_REQUIRE(means3D && opacities && viewmatrix && projmatrix && campos, "preprocess_fwd: null input");
   GSR_REQUIRE(records && radii && depth_keys && sort_vals, "preprocess_fwd: null output");
   GSR_REQUIRE((shs != nullptr) != (colors_precomp != nullptr), "preprocess_fwd: give exactly one of shs / colors_precomp");
@@ -707,7 +708,7 @@ extern "C" int gsr_preprocess_fwd(int P, int D, int M, const float* means3D, con
   FwdArgs a{0, 0, reference_lists, P, M, W, H, means3D, scales, rotations, opacities, shs, nullptr, colors_precomp, cov3D_precomp,
             viewmatrix, projmatrix, campos, scale_modifier, tanfovx, tanfovy, pack, records, radii, tiles_touched,
             depth_keys, rects, (unsigned long long*)sort_vals, nullptr, visible};
-  return launch_preprocess_fwd("preprocess_fwd", a, D, totals, stream);
+  return launch_preprocess_fwd("preprocess_fwd", a, D, totals, status, stream);
 }
 
 extern "C" int gsr_mark_visible(int P, const float* means3D, const float* viewmatrix, uint8_t* present,
@@ -769,10 +770,11 @@ extern "C" int gsr_preprocess_fwd_raw(int P, int D, int n_rest, const float* xyz
                                       int H, float tanfovx, float tanfovy, int reference_lists, uint32_t* records,
                                       int32_t* radii,
                                       uint32_t* tiles_touched, uint32_t* depth_keys, uint32_t* rects,
-                                      uint64_t* sort_vals, uint32_t* totals, uint8_t* visible, void* stream) {
+                                      uint64_t* sort_vals, uint32_t* totals, const uint32_t* status,
+                                      uint8_t* visible, void* stream) {
   GSR_REQUIRE(P >= 0 && W > 0 && H > 0, "preprocess_fwd_raw: bad sizes P=%d W=%d H=%d", P, W, H);
   GSR_REQUIRE(totals && ((uintptr_t)totals & 15) == 0, "preprocess_fwd_raw: totals must be non-null and 16-byte aligned");
-  if (P == 0) return gsr::launch_totals_final(0, totals + 4, totals, (hipStream_t)stream);
+  if (P == 0) return gsr::launch_totals_final(0, totals + kTotalsHead, status, totals, (hipStream_t)stream);
   GSR_REQUIRE(xyz && scaling_raw && rotation_raw && opacity_raw && features_dc && viewmatrix && projmatrix && campos,
               "preprocess_fwd_raw: null input");
   GSR_REQUIRE(records && radii && depth_keys && sort_vals, "preprocess_fwd_raw: null output");
@@ -788,7 +790,7 @@ extern "C" int gsr_preprocess_fwd_raw(int P, int D, int n_rest, const float* xyz
             n_rest > 0 ? features_rest : nullptr, nullptr, nullptr, viewmatrix, projmatrix, campos, scale_modifier,
             tanfovx, tanfovy, pack, records, radii, tiles_touched, depth_keys, rects, (unsigned long long*)sort_vals,
             nullptr, visible};
-  return launch_preprocess_fwd("preprocess_fwd_raw", a, D, totals, stream);
+  return launch_preprocess_fwd("preprocess_fwd_raw", a, D, totals, status, stream);
 }
 
 extern "C" int gsr_preprocess_bwd_raw(int P, int D, int n_rest, const float* xyz, const float* scaling_raw,

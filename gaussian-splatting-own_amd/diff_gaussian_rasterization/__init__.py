@@ -21,6 +21,7 @@ from __future__ import annotations
 
 import ctypes as C
 import os
+import threading
 from typing import NamedTuple, Optional
 
 import torch
@@ -57,20 +58,27 @@ def _load():
     lib.gsr_totals_words.restype = C.c_size_t
     lib.gsr_totals_words.argtypes = [ci]
     lib.gsr_preprocess_fwd.argtypes = [ci, ci, ci, vp, vp, cf, vp, vp, vp, vp, vp, vp, vp, vp, ci, ci, cf, cf, ci, ci,
-                                       vp, vp, vp, vp, vp, vp, vp, vp, vp]
+                                       vp, vp, vp, vp, vp, vp, vp, vp, vp, vp]
     lib.gsr_mark_visible.argtypes = [ci, vp, vp, vp, vp]
     u32 = C.c_uint32
     lib.gsr_bin_sort.argtypes = [ci, vp, vp, vp, vp, C.c_size_t, vp]
     lib.gsr_bin_sort_status.argtypes = [ci, vp, C.c_size_t, vp]
     lib.gsr_debug_sort_spin_limit.argtypes = [u32]
     lib.gsr_debug_sort_spin_limit.restype = None
-    lib.gsr_bin_lists.argtypes = [ci, u32, u32, u32, u32, ci, ci, vp, vp, vp, vp, vp, C.c_size_t, vp]
+    lib.gsr_bin_sort_error_word.argtypes = [vp]
+    lib.gsr_bin_sort_error_word.restype = vp
+    lib.gsr_bin_lists.argtypes = [ci, u32, u32, u32, u32, ci, ci, vp, vp, vp, vp, vp, vp, vp, vp, C.c_size_t, vp]
     lib.gsr_blend_fwd.argtypes = [ci, ci, vp, vp, vp, vp, vp, vp, vp, vp]
     lib.gsr_blend_bwd.argtypes = [ci, ci, vp, vp, vp, vp, vp, vp, vp, vp, vp]
+    lib.gsr_blend_fwd_timed.argtypes = [ci, ci, vp, vp, vp, vp, vp, vp, vp, vp, vp, vp]
+    lib.gsr_blend_bwd_timed.argtypes = [ci, ci, vp, vp, vp, vp, vp, vp, vp, vp, vp, vp, vp]
+    lib.gsr_event_create.restype = vp
+    lib.gsr_event_destroy.argtypes, lib.gsr_event_destroy.restype = [vp], None
+    lib.gsr_event_elapsed_ms.argtypes = [vp, vp, C.POINTER(C.c_float)]
     lib.gsr_preprocess_bwd.argtypes = [ci, ci, ci, vp, vp, cf, vp, vp, vp, vp, vp, vp, ci, ci, cf, cf, vp, vp,
                                        vp, vp, vp, vp, vp, vp, vp, vp, vp]
     lib.gsr_preprocess_fwd_raw.argtypes = [ci, ci, ci, vp, vp, cf, vp, vp, vp, vp, vp, vp, vp, ci, ci, cf, cf, ci,
-                                           vp, vp, vp, vp, vp, vp, vp, vp, vp]
+                                           vp, vp, vp, vp, vp, vp, vp, vp, vp, vp]
     lib.gsr_preprocess_bwd_raw.argtypes = [ci, ci, ci, vp, vp, cf, vp, vp, vp, vp, vp, vp, vp, ci, ci, cf, cf,
                                            vp, vp, vp, vp, vp, vp, vp, vp, vp, vp]
     return lib
@@ -84,11 +92,47 @@ class StageTimer:
     ``set_stage_timer``, every C-ABI call is bracketed by a pair of events on
     the current stream (the stream the kernels run on).  ``only`` restricts the brackets to the
     named stages: each bracket costs a few microseconds of device idle time, so a timed region
-    that is itself being measured should carry as few as it can."""
+    that is itself being measured should carry as few as it can.  Stages named in ``exact`` (the two
+    blend kernels can be) are not bracketed at all: their launch stamps a pair of events with the
+    kernel's own start and end (gsr_blend_*_timed), the duration a profiler's kernel trace reports,
+    at no cost to the stream; ``exact_ms`` returns those."""
 
-    def __init__(self, only=None):
+    EXACT_STAGES = ("blend_fwd", "blend_bwd")
+
+    def __init__(self, only=None, exact=()):
         self.events = {}
         self.only = None if only is None else frozenset(only)
+        self.exact = frozenset(exact)
+        if not self.exact <= frozenset(self.EXACT_STAGES):
+            raise ValueError(f"kernel-exact timing exists for {self.EXACT_STAGES} only")
+        self.kernel_events = {}
+
+    def kernel_pair(self, name):
+        pair = (_lib.gsr_event_create(), _lib.gsr_event_create())
+        if not pair[0] or not pair[1]:
+            raise RuntimeError("libgsr_hip: " + _lib.gsr_last_error().decode())
+        self.kernel_events.setdefault(name, []).append(pair)
+        return C.c_void_p(pair[0]), C.c_void_p(pair[1])
+
+    def exact_ms(self):
+        """Waits for the kernels, then {stage: (mean, min, max) milliseconds of the kernel itself, launches}."""
+        out = {}
+        for name, pairs in self.kernel_events.items():
+            ms = []
+            for a, b in pairs:
+                v = C.c_float()
+                if _lib.gsr_event_elapsed_ms(C.c_void_p(a), C.c_void_p(b), C.byref(v)) != 0:
+                    raise RuntimeError("libgsr_hip: " + _lib.gsr_last_error().decode())
+                ms.append(float(v.value))
+            out[name] = (sum(ms) / len(ms), min(ms), max(ms), len(ms))
+        return out
+
+    def close(self):
+        for pairs in self.kernel_events.values():
+            for a, b in pairs:
+                _lib.gsr_event_destroy(C.c_void_p(a))
+                _lib.gsr_event_destroy(C.c_void_p(b))
+        self.kernel_events = {}
 
     def bracket(self, name):
         e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
@@ -124,6 +168,17 @@ def _run(what: str, fn, *args) -> None:
         raise RuntimeError(f"libgsr_hip {what} failed ({rc}): {_lib.gsr_last_error().decode()}")
 
 
+def _run_blend(what: str, fn, fn_timed, *args) -> None:
+    """A blend launch; ``args`` without the trailing stream.  Kernel-exact events when the installed timer asks."""
+    if _timer is not None and what in _timer.exact:
+        start, stop = _timer.kernel_pair(what)
+        rc = fn_timed(*args, start, stop, _stream())
+        if rc != 0:
+            raise RuntimeError(f"libgsr_hip {what} failed ({rc}): {_lib.gsr_last_error().decode()}")
+    else:
+        _run(what, fn, *args, _stream())
+
+
 def _ptr(t: Optional[torch.Tensor]):
     return None if t is None else C.c_void_p(t.data_ptr())
 
@@ -132,27 +187,64 @@ def _stream():
     return C.c_void_p(torch.cuda.current_stream().cuda_stream)
 
 
-_pinned = {}
-_side = {}
+# Host-side helpers a forward keeps between calls, one set per (host thread, device): two threads that
+# render on one device (each on its own stream) never share a landing buffer, a side stream or a
+# status word.  The library itself keeps no state.
+_local = threading.local()
+TOTALS_HEAD = 8            # words the host reads back: N, E1, E2, V, status, 3 spare (gsr_totals_words)
+STATUS_SORT, STATUS_TOTALS = 1, 2
+
+
+def _per_device(dev: torch.device) -> dict:
+    slots = getattr(_local, "slots", None)
+    if slots is None:
+        slots = _local.slots = {}
+    key = dev.index if dev.index is not None else torch.cuda.current_device()
+    d = slots.get(key)
+    if d is None:
+        d = slots[key] = {}
+    return d
 
 
 def _side_stream(dev: torch.device) -> torch.cuda.Stream:
-    """A second stream (default priority) for work off the critical path, one per device."""
-    key = dev.index if dev.index is not None else torch.cuda.current_device()
-    st = _side.get(key)
-    if st is None:
-        st = _side[key] = torch.cuda.Stream(device=dev)
-    return st
+    """A second stream (default priority) for work off the critical path."""
+    d = _per_device(dev)
+    if "side" not in d:
+        d["side"] = torch.cuda.Stream(device=dev)
+    return d["side"]
 
 
 def _pinned_totals(dev: torch.device) -> torch.Tensor:
-    """Page-locked landing buffer for the four list sizes, one per device.  Every forward waits
-    for its own copy before reading it, so successive calls of one thread can share it."""
-    key = (dev.type, dev.index if dev.index is not None else torch.cuda.current_device())
-    buf = _pinned.get(key)
-    if buf is None:
-        buf = _pinned[key] = torch.empty((4,), dtype=torch.int32, pin_memory=True)
-    return buf
+    """Page-locked landing buffer for the list sizes and the status word.  Every forward waits
+    for its own copy before reading it, so the successive calls of one thread can share it."""
+    d = _per_device(dev)
+    if "pinned" not in d:
+        d["pinned"] = torch.empty((TOTALS_HEAD,), dtype=torch.int32, pin_memory=True)
+    return d["pinned"]
+
+
+def _status_word(dev: torch.device) -> torch.Tensor:
+    """The device-side status word of this thread's forwards on ``dev`` (see gsr_bin_lists in gsr.h): a
+    list builder that refuses to run (its depth sort gave up, or it was handed stale list sizes) sets a
+    bit here, and the next forward's read-back of the list sizes brings it to the host."""
+    d = _per_device(dev)
+    if "status" not in d:
+        d["status"] = torch.zeros((4,), dtype=torch.int32, device=dev)
+    return d["status"]
+
+
+class RasterizerFault(RuntimeError):
+    """A forward on this thread and device did not build its tile lists (status bits in ``.status``);
+    its image was the background colour and its backward added nothing."""
+
+    def __init__(self, status: int):
+        why = []
+        if status & STATUS_SORT:
+            why.append("its depth sort gave up waiting (GSR_E_SORT)")
+        if status & STATUS_TOTALS:
+            why.append("it was handed list sizes that were not its own")
+        super().__init__("libgsr_hip: an earlier forward built no tile lists: " + "; ".join(why or [hex(status)]))
+        self.status = status
 
 
 def _f32(t: Optional[torch.Tensor], name: str) -> Optional[torch.Tensor]:
@@ -269,8 +361,9 @@ def rasterize_forward(s: GaussianRasterizationSettings, means3D, opacities, shs=
         ref_lists = int(REFERENCE_LISTS if reference_lists is None else reference_lists)
         totals = torch.empty((_lib.gsr_totals_words(P),), **u32)
         sort_vals = torch.empty((P,), dtype=torch.int64, device=dev)
+        status = _status_word(dev)
         outs = (_ptr(st.records), _ptr(st.radii), None, _ptr(st.depth_keys), None,
-                _ptr(sort_vals), _ptr(totals), _ptr(st.visible), stream)
+                _ptr(sort_vals), _ptr(totals), _ptr(status), _ptr(st.visible), stream)
         if raw is not None:
             r = {k: _f32(v, k) for k, v in raw.items()}
             n_rest = 0 if r["features_rest"] is None else r["features_rest"].shape[1]
@@ -299,30 +392,37 @@ def rasterize_forward(s: GaussianRasterizationSettings, means3D, opacities, shs=
         # The list sizes go to the host (the pipeline's one read-back) while the GPU sorts by depth:
         # the copy is queued before the sort and the host waits for the copy alone.
         host = _pinned_totals(dev)
-        host.copy_(totals[:4], non_blocking=True)
+        host.copy_(totals[:TOTALS_HEAD], non_blocking=True)
         copied = torch.cuda.Event()
         copied.record()
         nb = _lib.gsr_bin_sort_bytes(P)
-        scratch = torch.empty((nb,), dtype=torch.uint8, device=dev)
+        sort_scratch = torch.empty((nb,), dtype=torch.uint8, device=dev)
         _run("bin_sort", _lib.gsr_bin_sort, P, _ptr(st.depth_keys), _ptr(sort_vals), _ptr(st.sorted_vals),
-             _ptr(scratch), nb, stream)
+             _ptr(sort_scratch), nb, stream)
+        sort_error = C.c_void_p(_lib.gsr_bin_sort_error_word(_ptr(sort_scratch)))
         if s.debug:
-            # the sort's bounded waits report a failure through a word that only a synchronising call reads
-            _run("bin_sort_status", _lib.gsr_bin_sort_status, P, _ptr(scratch), nb, stream)
+            # a synchronising check, as the replaced module synchronises after every stage in this mode
+            _run("bin_sort_status", _lib.gsr_bin_sort_status, P, _ptr(sort_scratch), nb, stream)
         copied.synchronize()
-        N, E1, E2, V = (int(v) & 0xFFFFFFFF for v in host.tolist())
+        N, E1, E2, V, carried = (int(v) & 0xFFFFFFFF for v in host.tolist()[:5])
+        if carried:
+            # an earlier forward of this thread refused to build its lists; this one has not been hurt
+            # (it is abandoned here, before its own lists are built)
+            status.zero_()
+            raise RasterizerFault(carried)
     st.num_rendered, st.num_visible = N, V
     st.point_list = torch.empty((max(N, 1),), **u32)
     if keep_tile_ids:
         st.tile_ids_sorted = torch.empty((max(N, 1),), **u32)
     nb = _lib.gsr_bin_lists_bytes(V, E1, E2, W, H)
     scratch = torch.empty((nb,), dtype=torch.uint8, device=dev)
+    guards = (sort_error, _ptr(totals), _ptr(status)) if P > 0 else (None, None, None)
     _run("bin_lists", _lib.gsr_bin_lists, P, V, N, E1, E2, W, H, _ptr(st.sorted_vals), _ptr(st.point_list),
-         _ptr(st.ranges), _ptr(st.tile_ids_sorted), _ptr(scratch), nb, stream)
+         _ptr(st.ranges), _ptr(st.tile_ids_sorted), *guards, _ptr(scratch), nb, stream)
     if st.dsplat is not None:
         torch.cuda.current_stream(dev).wait_event(cleared)
-    _run("blend_fwd", _lib.gsr_blend_fwd, W, H, _ptr(st.ranges), _ptr(st.point_list), _ptr(st.records), _ptr(st.bg),
-                              _ptr(st.color), _ptr(st.final_T), _ptr(st.n_contrib), stream)
+    _run_blend("blend_fwd", _lib.gsr_blend_fwd, _lib.gsr_blend_fwd_timed, W, H, _ptr(st.ranges), _ptr(st.point_list),
+               _ptr(st.records), _ptr(st.bg), _ptr(st.color), _ptr(st.final_T), _ptr(st.n_contrib))
     st.point_list = st.point_list[:N]
     if keep_tile_ids:
         st.tile_ids_sorted = st.tile_ids_sorted[:N]
@@ -336,8 +436,9 @@ def blend_backward(st: ForwardState, grad_color: torch.Tensor) -> torch.Tensor:
     if dsplat is None:
         dsplat = torch.zeros((st.P, GRAD_WORDS), dtype=torch.float32, device=grad_color.device)
     if st.P > 0 and st.num_rendered > 0:
-        _run("blend_bwd", _lib.gsr_blend_bwd, st.W, st.H, _ptr(st.ranges), _ptr(st.point_list), _ptr(st.records), _ptr(st.bg),
-                                  _ptr(st.final_T), _ptr(st.n_contrib), _ptr(grad_color), _ptr(dsplat), _stream())
+        _run_blend("blend_bwd", _lib.gsr_blend_bwd, _lib.gsr_blend_bwd_timed, st.W, st.H, _ptr(st.ranges),
+                   _ptr(st.point_list), _ptr(st.records), _ptr(st.bg), _ptr(st.final_T), _ptr(st.n_contrib),
+                   _ptr(grad_color), _ptr(dsplat))
     return dsplat
 
 
@@ -352,7 +453,7 @@ def splat_sums_to_grads(st: ForwardState, dsplat: torch.Tensor) -> dict:
     mean2D = torch.stack([-(A * m[:, 1] + B * m[:, 2]) * (0.5 * st.W), -(Cc * m[:, 2] + B * m[:, 1]) * (0.5 * st.H)], 1)
     conic = torch.stack([-0.5 * m[:, 3], -m[:, 4], -0.5 * m[:, 5]], 1)
     return dict(mean2D=torch.where(vis[:, None], mean2D, z[:, None]), conic=torch.where(vis[:, None], conic, z[:, None]),
-                opacity=torch.where(vis, m[:, 0] / o, z), color=torch.where(vis[:, None], m[:, 6:9], z[:, None]))
+                opacity=torch.where(vis & (o > 0), m[:, 0] / o, z), color=torch.where(vis[:, None], m[:, 6:9], z[:, None]))
 
 
 def rasterize_backward(s: GaussianRasterizationSettings, st: ForwardState, grad_color, means3D, shs=None,

@@ -43,7 +43,9 @@ def multiview_step(cameras: Sequence, render_view: Callable, loss_fn: Callable, 
                    rank: int = 0, world: int = 1, backward: bool = True):
     """Renders this rank's share of ``cameras``, back-propagates each view's
     loss (scaled by 1/len(cameras), so that gradients are those of the mean
-    loss over ALL views once they are summed over ranks), and returns
+    loss over ALL views once they are summed over ranks: exchange them with
+    ``all_reduce_gradients(..., average=False)`` / ``GradArena.all_reduce(average=False)``,
+    nothing is left for the optimiser step to scale), and returns
     (mean loss over all views and ranks, list of this rank's view indices)."""
     mine = views_for_rank(len(cameras), rank, world)
     total = None

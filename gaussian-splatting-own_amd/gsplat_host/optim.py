@@ -83,9 +83,12 @@ class GradArena:
     def zero_(self) -> None:
         self.flat.zero_()
 
-    def all_reduce(self, group=None) -> float:
-        """Sums the gradients over the ranks of ``group`` in one collective; returns the factor
-        (1 / world size) that turns the sum into the mean, to be applied by the optimiser step.
+    def all_reduce(self, group=None, average: bool = True) -> float:
+        """Sums the gradients over the ranks of ``group`` in one collective and returns the factor the
+        optimiser step still has to apply: 1 / world size when every rank back-propagated its own
+        un-normalised loss (``average``, the default: sum -> mean over ranks), 1.0 when the losses were
+        already scaled so that their sum over ranks IS the wanted gradient (``average=False``: what
+        ``multiview_step`` does, it divides every view's loss by the global view count).
         Without an initialised process group this is a no-op with factor 1."""
         if not (dist.is_available() and dist.is_initialized()):
             return 1.0
@@ -97,14 +100,16 @@ class GradArena:
                 self.flat.copy_(host)
             else:
                 dist.all_reduce(self.flat, op=dist.ReduceOp.SUM, group=group)
-        return 1.0 / world
+        return 1.0 / world if average else 1.0
 
 
-def all_reduce_gradients(params: Dict[str, torch.Tensor], group=None) -> float:
+def all_reduce_gradients(params: Dict[str, torch.Tensor], group=None, average: bool = True) -> float:
     """Sums ``param.grad`` of every tensor over the ranks, all collectives in flight together
     (the 45-coefficient SH gradient is 3/4 of the bytes; coalescing the small ones buys nothing
-    next to it), and returns 1 / world size for the optimiser step to apply.  For gradients
-    that already sit in a GradArena use its single-collective ``all_reduce`` instead."""
+    next to it), and returns the factor left for the optimiser step to apply: 1 / world size, or
+    1.0 with ``average=False`` (losses already normalised over all ranks' views, as
+    ``multiview_step`` does; see GradArena.all_reduce).  For gradients that already sit in a
+    GradArena use its single-collective ``all_reduce`` instead."""
     if not (dist.is_available() and dist.is_initialized()):
         return 1.0
     world = dist.get_world_size(group)
@@ -122,15 +127,16 @@ def all_reduce_gradients(params: Dict[str, torch.Tensor], group=None) -> float:
                 pending.append(dist.all_reduce(p.grad, op=dist.ReduceOp.SUM, group=group, async_op=True))
         for w in pending:
             w.wait()
-    return 1.0 / world
+    return 1.0 / world if average else 1.0
 
 
 class GaussianAdam:
     """torch.optim.Adam as the reference configures it (scene/gaussian_model.py:154-163), fused.
 
     ``params``: name -> tensor, in the reference's group names (xyz, f_dc, f_rest, opacity, scaling,
-    rotation); ``lrs``: name -> learning rate.  State (exp_avg, exp_avg_sq, step) matches
-    torch.optim.Adam's, so a reference checkpoint's optimiser state maps one to one."""
+    rotation); ``lrs``: name -> learning rate.  State (exp_avg, exp_avg_sq, step) is what
+    torch.optim.Adam keeps per parameter; ``state_dict`` / ``load_state_dict`` exchange it in that
+    optimiser's layout."""
 
     def __init__(self, params: Dict[str, torch.Tensor], lrs: Dict[str, float], betas=(0.9, 0.999),
                  eps: float = 1e-15):

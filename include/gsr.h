@@ -19,6 +19,11 @@
  *    memory (the Python layer hands out torch caching-allocator memory);
  *    scratch sizes come from the *_bytes functions.  Scratch must be 256-byte
  *    aligned.
+ *  - The library keeps no state between calls and every entry point may be
+ *    called from several host threads at once, each on its own stream, as long
+ *    as no two calls in flight share an output, scratch or status buffer.  The
+ *    one exception is the patience setting of gsr_debug_sort_spin_limit (a test
+ *    hook, process-wide).
  *  - `stream` is a hipStream_t passed as void* (NULL = the null stream).
  *    Calls only enqueue work; none synchronises.  The one host read-back the
  *    pipeline needs (the list sizes, after gsr_preprocess_fwd) is done by the
@@ -41,13 +46,18 @@
 extern "C" {
 #endif
 
-#define GSR_VERSION 1
+#define GSR_VERSION 2
 
 #define GSR_OK 0
 #define GSR_E_INVALID (-1)   /* bad argument (null pointer, negative size, unsupported M/D) */
 #define GSR_E_LAUNCH (-2)    /* HIP reported an error on launch / enqueue                    */
 #define GSR_E_SCRATCH (-3)   /* scratch buffer too small or misaligned                       */
 #define GSR_E_SORT (-4)      /* the depth sort gave up waiting (see gsr_bin_sort_status)     */
+#define GSR_E_TOO_LARGE (-5) /* the input exceeds a fixed capacity (gsr_bin_sort_static)      */
+
+/* Bits of the caller's device-side status word (see gsr_bin_lists). */
+#define GSR_STATUS_SORT 1u   /* a list builder found that its depth sort had given up        */
+#define GSR_STATUS_TOTALS 2u /* a list builder was handed list sizes other than the preprocess's */
 
 /* One 64-byte record per Gaussian, written by gsr_preprocess_fwd and read by
  * the binning and blending kernels: everything a tile needs about a splat in
@@ -99,6 +109,9 @@ const char* gsr_last_error(void);
  * back (the pipeline's one host read-back; it can overlap gsr_bin_sort) to size
  * gsr_bin_lists.  totals has gsr_totals_words(P) words (the rest is the call's
  * scratch) and is 16-byte aligned.
+ * status (may be NULL): the caller's device-side status word, see gsr_bin_lists;
+ * its value at this point is copied to totals[4], so that it reaches the host with
+ * the list sizes at no extra cost (totals[5..7] are reserved).
  *
  * visible (P) uint8, optional (may be NULL): radii > 0, the `visibility_filter`
  * render() returns (gaussian_renderer/__init__.py:99).
@@ -121,7 +134,7 @@ int gsr_preprocess_fwd(int P, int D, int M, const float* means3D, const float* s
                        int W, int H, float tanfovx, float tanfovy, int prefiltered,
                        int reference_lists, uint32_t* records, int32_t* radii, uint32_t* tiles_touched,
                        uint32_t* depth_keys, uint32_t* rects, uint64_t* sort_vals,
-                       uint32_t* totals, uint8_t* visible, void* stream);
+                       uint32_t* totals, const uint32_t* status, uint8_t* visible, void* stream);
 
 /* GaussianRasterizer.markVisible of the module (never called by the
  * reference's Python): present[i] = view-space z > 0.2. */
@@ -159,9 +172,14 @@ int gsr_bin_sort(int P, const uint32_t* depth_keys, const uint64_t* sort_vals,
  * gave up (sorted_vals is then incomplete).  The Python module calls it when
  * the settings' `debug` flag is set (gaussian_renderer/__init__.py:48), as the
  * replaced module synchronises and checks for errors in that mode.
+ * A sort that gave up writes nothing outside its scratch and sorted_vals[0 .. P).
+ * gsr_bin_sort_error_word returns the DEVICE address, inside the sort's scratch,
+ * of the word that is non-zero after such a sort: hand it to gsr_bin_lists, which
+ * then refuses to build lists from an incomplete sort, without any host wait.
  * gsr_debug_sort_spin_limit sets the patience of later sorts in look-back
  * steps (0 = default); it exists for tests of this path. */
 int gsr_bin_sort_status(int P, const void* scratch, size_t scratch_bytes, void* stream);
+const uint32_t* gsr_bin_sort_error_word(const void* sort_scratch);
 void gsr_debug_sort_spin_limit(uint32_t limit);
 
 /* gsr_bin_lists: point_list (N) uint32 = Gaussian index per sorted instance;
@@ -169,12 +187,25 @@ void gsr_debug_sort_spin_limit(uint32_t limit);
  * empty tiles.
  * tile_ids_sorted (N) uint32 is optional (may be NULL): the tile id of each
  * sorted instance, from which the module's 64-bit sort keys are
- * (tile << 32) | depth_key[point_list]. */
+ * (tile << 32) | depth_key[point_list].
+ *
+ * Three optional device pointers make the call safe against what the host cannot
+ * see when it enqueues it (each may be NULL = not checked):
+ *   sort_error  gsr_bin_sort_error_word of the sort that produced sorted_vals;
+ *   totals      the totals array of stage 1 (the device's own N, E1, E2, V);
+ *   status      one uint32 of the caller's, zeroed once, that outlives the call.
+ * If the sort gave up, or V / N / E1 / E2 differ from the device's totals (a stale
+ * or foreign read-back: the buffers were sized for other lists), the builder writes
+ * no list: every tile range becomes (0,0), so the image is the background and the
+ * backward a no-op, and GSR_STATUS_SORT / GSR_STATUS_TOTALS is OR-ed into *status.
+ * The next gsr_preprocess_fwd that is given the same status word carries it to the
+ * host in totals[4]: the failure surfaces one call late, for free, and nothing is
+ * ever written out of bounds in between. */
 size_t gsr_bin_lists_bytes(uint32_t V, uint32_t E1, uint32_t E2, int W, int H);
 int gsr_bin_lists(int P, uint32_t V, uint32_t N, uint32_t E1, uint32_t E2, int W, int H,
                   const uint64_t* sorted_vals, uint32_t* point_list, uint32_t* ranges,
-                  uint32_t* tile_ids_sorted, void* scratch, size_t scratch_bytes,
-                  void* stream);
+                  uint32_t* tile_ids_sorted, const uint32_t* sort_error, const uint32_t* totals,
+                  uint32_t* status, void* scratch, size_t scratch_bytes, void* stream);
 
 /* ---- Stage 3: blend forward ----------------------------------------------
  * Front-to-back alpha compositing per tile (the module's per-tile render
@@ -201,6 +232,25 @@ int gsr_blend_bwd(int W, int H, const uint32_t* ranges, const uint32_t* point_li
                   const uint32_t* records, const float* bg, const float* final_T,
                   const uint32_t* n_contrib, const float* dL_dpix, float* dL_dsplat,
                   void* stream);
+
+/* ---- Kernel-exact timing of the two blend kernels ----------------------------
+ * The same calls with a pair of events (hipEvent_t passed as void*, from
+ * gsr_event_create; either may be NULL) that the launch stamps with the kernel's
+ * own start and end, the interval a profiler's kernel trace reports: events
+ * recorded on the stream around a call also measure the gap before the kernel
+ * starts.  gsr_event_elapsed_ms waits for stop_event and writes the milliseconds
+ * between the two to *h_ms (host memory).  Measurement only: the reference has
+ * no counterpart (its two torch events span a whole iteration, train.py:44-45,67,95). */
+void* gsr_event_create(void);
+void gsr_event_destroy(void* event);
+int gsr_event_elapsed_ms(void* start_event, void* stop_event, float* h_ms);
+int gsr_blend_fwd_timed(int W, int H, const uint32_t* ranges, const uint32_t* point_list,
+                        const uint32_t* records, const float* bg, float* out_color, float* final_T,
+                        uint32_t* n_contrib, void* start_event, void* stop_event, void* stream);
+int gsr_blend_bwd_timed(int W, int H, const uint32_t* ranges, const uint32_t* point_list,
+                        const uint32_t* records, const float* bg, const float* final_T,
+                        const uint32_t* n_contrib, const float* dL_dpix, float* dL_dsplat,
+                        void* start_event, void* stop_event, void* stream);
 
 /* ---- Stage 5: preprocess backward ----------------------------------------
  * dL_dsplat -> gradients of the op's inputs (what autograd hands back to the
@@ -234,7 +284,7 @@ int gsr_preprocess_fwd_raw(int P, int D, int n_rest, const float* xyz, const flo
                            int W, int H, float tanfovx, float tanfovy, int reference_lists,
                            uint32_t* records, int32_t* radii, uint32_t* tiles_touched,
                            uint32_t* depth_keys, uint32_t* rects, uint64_t* sort_vals,
-                           uint32_t* totals, uint8_t* visible, void* stream);
+                           uint32_t* totals, const uint32_t* status, uint8_t* visible, void* stream);
 int gsr_preprocess_bwd_raw(int P, int D, int n_rest, const float* xyz, const float* scaling_raw,
                            float scale_modifier, const float* rotation_raw, const float* opacity_raw,
                            const float* features_dc, const float* features_rest,

@@ -23,7 +23,7 @@ def test_header_declares_the_expected_entry_points():
     syms = declared_symbols()
     for s in ("gsr_version", "gsr_last_error", "gsr_preprocess_fwd", "gsr_mark_visible", "gsr_totals_words",
               "gsr_bin_sort_bytes", "gsr_bin_sort", "gsr_bin_sort_status", "gsr_debug_sort_spin_limit",
-              "gsr_bin_lists_bytes", "gsr_bin_lists", "gsr_blend_fwd", "gsr_blend_bwd",
+              "gsr_bin_sort_error_word", "gsr_bin_lists_bytes", "gsr_bin_lists", "gsr_blend_fwd", "gsr_blend_bwd",
               "gsr_preprocess_bwd"):
         assert s in syms
 
@@ -35,7 +35,7 @@ def test_library_exports_every_declared_symbol():
     for s in declared_symbols():
         assert hasattr(lib, s), s
     lib.gsr_version.restype = ctypes.c_int
-    assert lib.gsr_version() == 1
+    assert lib.gsr_version() == 2
     lib.gsr_last_error.restype = ctypes.c_char_p
     assert isinstance(lib.gsr_last_error(), bytes)
 
@@ -73,12 +73,13 @@ def test_scratch_and_size_checks_come_before_any_launch():
     lib.gsr_totals_words.restype = ctypes.c_size_t
     vp, sz, u32 = ctypes.c_void_p, ctypes.c_size_t, ctypes.c_uint32
     lib.gsr_bin_sort.argtypes = [ctypes.c_int, vp, vp, vp, vp, sz, vp]
-    lib.gsr_bin_lists.argtypes = [ctypes.c_int, u32, u32, u32, u32, ctypes.c_int, ctypes.c_int, vp, vp, vp, vp, vp, sz, vp]
+    lib.gsr_bin_lists.argtypes = [ctypes.c_int, u32, u32, u32, u32, ctypes.c_int, ctypes.c_int, vp, vp, vp, vp, vp, vp, vp,
+                                  vp, sz, vp]
 
     sizes = [lib.gsr_bin_sort_bytes(p) for p in (0, 1, 4096, 4097, 1_000_000, 6_000_000)]
     assert all(s % 256 == 0 for s in sizes) and sizes == sorted(sizes)
     assert sizes[4] >= 24 * 1_000_000                      # two key and two value buffers
-    assert lib.gsr_totals_words(0) == 4 and lib.gsr_totals_words(257) == 4 + 4 * 2
+    assert lib.gsr_totals_words(0) == 8 and lib.gsr_totals_words(257) == 8 + 4 * 2
     assert lib.gsr_bin_lists_bytes(0, 0, 0, 1920, 1080) == 256
     assert lib.gsr_bin_lists_bytes(1000, 1200, 3000, 1920, 1080) % 256 == 0
 
@@ -96,10 +97,14 @@ def test_scratch_and_size_checks_come_before_any_launch():
     assert lib.gsr_bin_sort_status(1000, None, 1 << 20, None) == -1 and b"null" in lib.gsr_last_error()
     assert lib.gsr_bin_sort_status(1000, fake, 16, None) == -3
     assert lib.gsr_bin_sort_status(0, None, 0, None) == 0
+    lib.gsr_bin_sort_error_word.argtypes, lib.gsr_bin_sort_error_word.restype = [vp], vp
+    assert lib.gsr_bin_sort_error_word(None) is None
+    word = lib.gsr_bin_sort_error_word(vp(0x100000))       # pointer arithmetic only
+    assert 0x100000 < word < 0x100000 + lib.gsr_bin_sort_bytes(1) and word % 4 == 0
 
-    rc = lib.gsr_bin_lists(1000, 900, 5000, 800, 3000, 640, 480, fake, fake, fake, None, fake, 1 << 24, None)
+    rc = lib.gsr_bin_lists(1000, 900, 5000, 800, 3000, 640, 480, fake, fake, fake, None, None, None, None, fake, 1 << 24, None)
     assert rc == -1 and b"inconsistent totals" in lib.gsr_last_error()      # E1 < V
-    rc = lib.gsr_bin_lists(1000, 900, 5000, 950, 3000, 640, 480, fake, fake, fake, None, fake, 16, None)
+    rc = lib.gsr_bin_lists(1000, 900, 5000, 950, 3000, 640, 480, fake, fake, fake, None, None, None, None, fake, 16, None)
     assert rc != 0 and b"scratch too small" in lib.gsr_last_error()
-    rc = lib.gsr_bin_lists(1000, 900, 5000, 950, 3000, 70000, 480, fake, fake, fake, None, fake, 1 << 24, None)
+    rc = lib.gsr_bin_lists(1000, 900, 5000, 950, 3000, 70000, 480, fake, fake, fake, None, None, None, None, fake, 1 << 24, None)
     assert rc == -1 and b"too large" in lib.gsr_last_error()

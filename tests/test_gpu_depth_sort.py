@@ -83,23 +83,52 @@ def test_narrow_depth_range_many_groups():
     _check(_depth_keys(rng, P, 0.1, lo=5.0, hi=5.5), rng.integers(0, 2**63, P, dtype=np.uint64))
 
 
-def test_a_sort_that_runs_out_of_patience_says_so():
+@pytest.mark.parametrize("culled_fraction", [0.1, 0.0])
+def test_a_sort_that_runs_out_of_patience_says_so_and_stays_in_its_buffers(culled_fraction):
     """With a patience of one look-back step a workgroup that finds its predecessors' counts missing twice
     gives up: every kernel still ends, and the status call reports the failure (or, if no workgroup
-    happened to wait, a complete sort).  The default patience is back afterwards."""
+    happened to wait, a complete sort).  A failed sort must not write outside its scratch and the P
+    output words, whatever the scratch held before: the scratch is poisoned with 0xFF (keys that would
+    rank last, counts that are huge), input, output and scratch sit in one allocation between canaries,
+    and with nothing culled every slot of every buffer is in use.  The default patience is back afterwards."""
     import diff_gaussian_rasterization as dgr
     rng = np.random.default_rng(13)
     P = 1_000_000
-    keys, vals = _depth_keys(rng, P, 0.1), rng.integers(0, 2**63, P, dtype=np.uint64)
+    keys, vals = _depth_keys(rng, P, culled_fraction), rng.integers(0, 2**63, P, dtype=np.uint64)
     order = np.argsort(keys, kind="stable")
     order = order[keys[order] != CULLED]
+    nb = dgr._lib.gsr_bin_sort_bytes(P)
+    pad = 1 << 16
+    # [canary | out (8P) | canary | scratch (nb) | canary], everything 256-byte aligned
+    out_off, scr_off = pad, pad + 8 * P + pad
+    scr_off = (scr_off + 255) // 256 * 256
+    arena = torch.full((scr_off + nb + pad,), 0xA5, dtype=torch.uint8, device="cuda")
+    base = arena.data_ptr()
+    assert base % 256 == 0
+    arena[scr_off:scr_off + nb] = 0xFF
+    arena[out_off:out_off + 8 * P] = 0xEE
+    k = torch.from_numpy(keys.view(np.int32)).cuda()
+    v = torch.from_numpy(vals.view(np.int64)).cuda()
+    import ctypes as C
     dgr._lib.gsr_debug_sort_spin_limit(1)
     try:
-        got, rc, message = _sort(keys, vals, want_status=True)
+        dgr._run("bin_sort", dgr._lib.gsr_bin_sort, P, dgr._ptr(k), dgr._ptr(v), C.c_void_p(base + out_off),
+                 C.c_void_p(base + scr_off), nb, dgr._stream())
+        rc = dgr._lib.gsr_bin_sort_status(P, C.c_void_p(base + scr_off), nb, dgr._stream())
+        message = dgr._lib.gsr_last_error().decode()
     finally:
         dgr._lib.gsr_debug_sort_spin_limit(0)
+    host = arena.cpu().numpy()
+    for lo, hi in ((0, out_off), (out_off + 8 * P, scr_off), (scr_off + nb, len(host))):
+        assert (host[lo:hi] == 0xA5).all(), "the sort wrote outside its buffers"
+    assert np.array_equal(k.cpu().numpy().view(np.uint32), keys) and np.array_equal(v.cpu().numpy().view(np.uint64), vals)
+    got = host[out_off:out_off + 8 * P].view(np.uint64)
+    print("impatient sort: rc", rc, flush=True)
     if rc == 0:
         assert np.array_equal(got[:len(order)], vals[order])
     else:
         assert rc == -4 and "gave up" in message
+        # what was written is made of input values (or was never written)
+        written = got[got != np.uint64(0xEEEEEEEEEEEEEEEE)]
+        assert np.isin(written, vals).all()
     _check(keys, vals)

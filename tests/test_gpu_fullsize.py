@@ -2,10 +2,13 @@
 
 C2 (100k Gaussians, 800x800, degree 3) is still small enough for the CPU oracle,
 so it is compared directly, forward and backward.  C3 (1M Gaussians, 1920x1080)
-is checked through properties that do not need an oracle: the tile lists are
-sorted and partition the instances, a second run is bit-identical in the
-forward, the backward is linear in the incoming gradient, and the two
-interchangeable input paths agree.
+and C5 (6M Gaussians, half of them in a hot spot at the origin, 1920x1080: the
+tile-load skew stress) are checked through properties that do not need an
+oracle: the tile lists are sorted and partition the instances, a second run is
+bit-identical in the forward, the backward is linear in the incoming gradient,
+and the two interchangeable input paths agree.  C5 is also compared with the
+oracle directly on a thinned copy of its cloud (every 30th Gaussian: the hot
+tiles keep lists of thousands of entries).
 """
 import math
 
@@ -53,17 +56,32 @@ def test_c2_against_oracle(oracle32):
         assert e < 3e-5
 
 
-@pytest.fixture(scope="module")
-def c3():
+BIG = {
+    # name: (P, skew_fraction) at 1920x1080, SH degree 3: the benchmark's workloads of the same names
+    "c3": (1_000_000, 0.0),
+    "c5": (6_000_000, 0.5),
+}
+
+
+@pytest.fixture(scope="module", params=list(BIG))
+def c3(request):
+    """The forward state of one full-size workload (the fixture keeps its first name; it serves C3 and C5)."""
     import diff_gaussian_rasterization as dgr
-    P, W, H, deg = 1_000_000, 1920, 1080, 3
-    cloud, cam, bg, _ = make_scene(P, W, H, sh_degree=deg, seed=0)
+    P, skew = BIG[request.param]
+    W, H, deg = 1920, 1080, 3
+    cloud, cam, bg, _ = make_scene(P, W, H, sh_degree=deg, seed=0, skew_fraction=skew)
     s = _gpu_settings(cam, bg, deg, 1.0)
     c = cloud.to("cuda")
+    del cloud
     st = dgr.rasterize_forward(s, c.xyz, c.opacity, shs=c.features, scales=c.scaling, rotations=c.rotation,
                                keep_tile_ids=True, reference_lists=True)
     torch.cuda.synchronize()
-    return dgr, s, c, st
+    r = st.ranges.to(torch.int64)
+    print(request.param, "visible", st.num_visible, "instances", st.num_rendered, "longest tile list",
+          int((r[:, 1] - r[:, 0]).max()), flush=True)
+    yield dgr, s, c, st
+    del st, c
+    torch.cuda.empty_cache()
 
 
 def test_c3_lists_are_sorted_and_partition_the_instances(c3):
@@ -119,7 +137,7 @@ def test_c3_short_lists_give_the_same_image_and_gradients(c3):
     short = dgr.rasterize_forward(s, c.xyz, c.opacity, shs=c.features, scales=c.scaling, rotations=c.rotation,
                                   reference_lists=False)
     torch.cuda.synchronize()
-    print("C3 instances", st.num_rendered, "->", short.num_rendered, flush=True)
+    print("short lists: instances", st.num_rendered, "->", short.num_rendered, flush=True)
     assert short.num_rendered < st.num_rendered
     assert torch.equal(short.color, st.color) and torch.equal(short.final_T, st.final_T)
     assert torch.equal(short.radii, st.radii)
@@ -129,7 +147,7 @@ def test_c3_short_lists_give_the_same_image_and_gradients(c3):
     g_short = dgr.rasterize_backward(s, short, d, c.xyz, **kw)
     for nm in ("means3D", "means2D", "shs", "opacities", "scales", "rotations"):
         err = float((g_short[nm] - g_full[nm]).abs().max() / (g_full[nm].abs().max() + 1e-20))
-        print("C3 short lists", nm, "%.2e" % err, flush=True)
+        print("short lists", nm, "%.2e" % err, flush=True)
         assert err < 2e-5
 
 
@@ -145,7 +163,7 @@ def test_c3_backward_is_linear_in_the_incoming_gradient(c3):
     for nm in ("means3D", "means2D", "shs", "opacities", "scales", "rotations"):
         want = 0.5 * g1[nm] - 2.0 * g2[nm]
         err = float((g12[nm] - want).abs().max() / (want.abs().max() + 1e-20))
-        print("C3 linearity", nm, "%.2e" % err, flush=True)
+        print("linearity", nm, "%.2e" % err, flush=True)
         assert err < 2e-5
         vis = st.radii > 0
         assert float(g12[nm][~vis].abs().max()) == 0.0                 # culled Gaussians get exactly zero
@@ -166,3 +184,47 @@ def test_c3_interchangeable_input_paths(c3):
     assert float((st2.radii != st.radii).float().mean()) < 1e-4
     diff = (st2.color - st.color).abs()
     assert float(diff.mean()) < 1e-5 and float((diff > 1e-3).float().mean()) < 1e-3
+
+
+def test_c5_thinned_cloud_against_oracle(oracle32):
+    """Every 30th Gaussian of the C5 cloud (200k: half of them in the hot spot, whose tiles keep lists of
+    thousands of entries) at 1920x1080, against the CPU oracle: bit-exact preprocess and lists, images
+    within 1e-5, gradients within 3e-5."""
+    import diff_gaussian_rasterization as dgr
+    from gsplat_host.synthetic import Cloud
+    P, W, H, deg = 6_000_000, 1920, 1080, 3
+    full, cam, bg, _ = make_scene(P, W, H, sh_degree=deg, seed=0, skew_fraction=0.5)
+    pick = torch.arange(0, P, 30)
+    cloud = Cloud(*(getattr(full, k)[pick].contiguous() for k in ("xyz", "opacity", "scaling", "rotation", "features")),
+                  full.sh_degree)
+    del full
+    s_cpu, s_gpu = oracle_settings(cam, bg, deg), _gpu_settings(cam, bg, deg, 1.0)
+    cn = cloud_numpy(cloud)
+    ref = oracle32.forward(s_cpu, **cn)
+    c = cloud.to("cuda")
+    st = dgr.rasterize_forward(s_gpu, c.xyz, c.opacity, shs=c.features, scales=c.scaling, rotations=c.rotation,
+                               keep_tile_ids=True, reference_lists=True)
+    torch.cuda.synchronize()
+    rr = ref["bin"]["ranges"].astype(np.int64).reshape(-1, 2)
+    print("C5/30: visible", int((ref["radii"] > 0).sum()), "instances", ref["bin"]["n_dup"], "longest tile list",
+          int((rr[:, 1] - rr[:, 0]).max()), flush=True)
+    assert int((rr[:, 1] - rr[:, 0]).max()) > 2000
+    assert np.array_equal(st.radii.cpu().numpy(), ref["radii"])
+    assert np.array_equal(st.point_list.cpu().numpy().view(np.uint32), ref["bin"]["point_list"])
+    assert np.array_equal(st.sort_keys().cpu().numpy().view(np.uint64), ref["bin"]["keys"])
+    assert np.array_equal(st.ranges.cpu().numpy().view(np.uint32), ref["bin"]["ranges"])
+    safe = ref["fwd"]["margin"] >= MARGIN_SAFE
+    assert 1.0 - safe.mean() < 5e-3
+    diff = np.abs(st.color.cpu().numpy() - ref["color"])
+    assert diff[:, safe].max() <= PIX_TOL
+    assert np.array_equal(st.n_contrib.cpu().numpy().view(np.uint32)[safe], ref["fwd"]["n_contrib"][safe])
+    dL = np.random.default_rng(2).standard_normal((3, H, W)).astype(np.float32) * safe[None]
+    g_ref = oracle32.backward(s_cpu, ref, dL, cn["means3D"], scales=cn["scales"], rotations=cn["rotations"],
+                              shs=cn["shs"])
+    g = dgr.rasterize_backward(s_gpu, st, torch.from_numpy(dL).cuda(), c.xyz, shs=c.features, scales=c.scaling,
+                               rotations=c.rotation)
+    for nm in ("means3D", "means2D", "shs", "opacities", "scales", "rotations"):
+        got = g[nm].cpu().numpy()
+        e = _rel_err(got, g_ref[nm].reshape(got.shape))
+        print("C5/30 grad", nm, "rel err %.2e" % e, flush=True)
+        assert e < 3e-5

@@ -1,0 +1,190 @@
+"""Edges of the operator that the parity scenes do not reach: opacity exactly zero, the reference's own
+gradient-sink idiom, and what happens when the tile lists cannot be built (a depth sort that gave up, list
+sizes that are not the call's own).  Failures are forced from the host: a patience of one look-back step,
+a flag word the test sets itself.  Every kernel still ends normally."""
+import math
+
+import numpy as np
+import pytest
+import torch
+
+from scenes import make_scene
+from test_gpu_parity import _gpu_settings
+
+pytestmark = pytest.mark.gpu
+
+
+def test_opacity_exactly_zero_gives_zero_gradients_not_nan():
+    """A visible Gaussian with opacity 0 blends nowhere; its opacity gradient is 0 (sum of G dL/dalpha over
+    no pixel), not 0/0.  Both entry points: activated opacities with exact zeros, raw opacities of -200
+    (sigmoid underflows to 0)."""
+    import diff_gaussian_rasterization as dgr
+    from gsplat_host.model import GaussianParams
+    from gsplat_host.render import PipelineParams, render
+    P, W, H = 6_000, 256, 160
+    cloud, cam, bg, _ = make_scene(P, W, H, sh_degree=2, seed=31, bg=(0.2, 0.1, 0.3), coeffs=9)
+    s = _gpu_settings(cam, bg, 2, 1.0)
+    c = cloud.to("cuda")
+    dead = torch.arange(P, device="cuda") % 3 == 0
+    op = c.opacity.clone()
+    op[dead] = 0.0
+    leaf = lambda t: t.clone().requires_grad_(True)
+    m3, opl, sc, ro, sh = leaf(c.xyz), leaf(op), leaf(c.scaling), leaf(c.rotation), leaf(c.features)
+    sink = torch.zeros_like(m3, requires_grad=True)
+    img, radii = dgr.GaussianRasterizer(raster_settings=s)(means3D=m3, means2D=sink, shs=sh, colors_precomp=None,
+                                                           opacities=opl, scales=sc, rotations=ro, cov3D_precomp=None)
+    w = torch.randn(img.shape, device="cuda", generator=torch.Generator(device="cuda").manual_seed(1))
+    (img * w).sum().backward()
+    vis_dead = dead & (radii > 0)
+    assert int(vis_dead.sum()) > 100
+    for t in (m3, opl, sc, ro, sh, sink):
+        assert bool(torch.isfinite(t.grad).all())
+    assert float(opl.grad[vis_dead].abs().max()) == 0.0
+    assert float(sink.grad[vis_dead].abs().max()) == 0.0 and float(m3.grad[vis_dead].abs().max()) == 0.0
+    assert float(opl.grad[~dead & (radii > 0)].abs().max()) > 0.0
+
+    # the image is the one rendered without the dead Gaussians at all
+    keep = ~dead
+    st = dgr.rasterize_forward(s, c.xyz[keep].contiguous(), op[keep].contiguous(), shs=c.features[keep].contiguous(),
+                               scales=c.scaling[keep].contiguous(), rotations=c.rotation[keep].contiguous())
+    assert torch.equal(st.color, img.detach())
+
+    model = GaussianParams(cloud, max_sh_degree=2, device="cuda")
+    with torch.no_grad():
+        model._opacity[dead] = -200.0
+    out = render(cam.to("cuda"), model, PipelineParams(fused_activations=True), bg.cuda())
+    (out["render"] * w).sum().backward()
+    for n, p in model.named_parameters():
+        if p.grad is not None:
+            assert bool(torch.isfinite(p.grad).all()), n
+    assert float(model._opacity.grad[dead].abs().max()) == 0.0
+    assert float((out["render"].detach() - img.detach()).abs().mean()) < 1e-5      # exp(log(s)) differs from s by ulps
+
+
+def test_the_reference_gradient_sink_idiom():
+    """gaussian_renderer/__init__.py:26-30: the sink is a NON-leaf (zeros_like(...) + 0) with retain_grad();
+    add_densification_stats reads its .grad[:, :2] (scene/gaussian_model.py:405-407)."""
+    import diff_gaussian_rasterization as dgr
+    cloud, cam, bg, _ = make_scene(5_000, 240, 160, sh_degree=3, seed=8)
+    s = _gpu_settings(cam, bg, 3, 1.0)
+    c = cloud.to("cuda")
+    xyz = c.xyz.clone().requires_grad_(True)
+    grads = {}
+    for idiom in ("reference", "leaf"):
+        if idiom == "reference":
+            screenspace_points = torch.zeros_like(xyz, dtype=xyz.dtype, requires_grad=True, device="cuda") + 0
+            try:
+                screenspace_points.retain_grad()
+            except Exception:          # as the reference: :27-30
+                pass
+            assert not screenspace_points.is_leaf
+        else:
+            screenspace_points = torch.zeros_like(xyz, requires_grad=True)
+        img, radii = dgr.GaussianRasterizer(raster_settings=s)(
+            means3D=xyz, means2D=screenspace_points, shs=c.features, colors_precomp=None, opacities=c.opacity,
+            scales=c.scaling, rotations=c.rotation, cov3D_precomp=None)
+        xyz.grad = None
+        img.square().sum().backward()
+        g = screenspace_points.grad
+        assert g is not None and g.shape == (5_000, 3)
+        grads[idiom] = g.clone()
+        vis = radii > 0
+        norm = torch.norm(g[vis, :2], dim=-1, keepdim=True)          # what the densifier accumulates
+        assert bool(torch.isfinite(norm).all()) and float(norm.max()) > 0.0
+        assert float(g[~vis].abs().max()) == 0.0 and float(g[:, 2].abs().max()) == 0.0
+    scale = float(grads["leaf"].abs().max())
+    assert float((grads["reference"] - grads["leaf"]).abs().max()) <= 2e-5 * scale      # float atomics: order differs
+
+
+def _forward(dgr, s, c, **kw):
+    return dgr.rasterize_forward(s, c.xyz, c.opacity, shs=c.features, scales=c.scaling, rotations=c.rotation, **kw)
+
+
+def test_list_builder_refuses_a_failed_sort_and_foreign_sizes():
+    """gsr_bin_lists with the guards of gsr.h, driven directly: a non-zero sort-error word, or list sizes
+    that differ from the device's own, make it write no list: all ranges (0,0), the status word says why,
+    and nothing outside the output buffers is touched (canaries)."""
+    import diff_gaussian_rasterization as dgr
+    lib, ptr = dgr._lib, dgr._ptr
+    cloud, cam, bg, _ = make_scene(20_000, 640, 360, sh_degree=0, seed=4, coeffs=1)
+    s = _gpu_settings(cam, bg, 0, 1.0)
+    c = cloud.to("cuda")
+    st = _forward(dgr, s, c)
+    torch.cuda.synchronize()
+    N, V = st.num_rendered, st.num_visible
+    # the device's totals of this scene, recomputed through the ABI
+    P, W, H = st.P, st.W, st.H
+    u32 = dict(dtype=torch.int32, device="cuda")
+    totals = torch.empty((lib.gsr_totals_words(P),), **u32)
+    records, radii, keys = torch.empty((P, 16), **u32), torch.empty((P,), **u32), torch.empty((P,), **u32)
+    sort_vals = torch.empty((P,), dtype=torch.int64, device="cuda")
+    dgr._run("preprocess_fwd", lib.gsr_preprocess_fwd, P, 0, 1, ptr(c.xyz), ptr(c.scaling), 1.0, ptr(c.rotation),
+             ptr(c.opacity), ptr(c.features), None, None, ptr(st.view), ptr(st.proj), ptr(st.campos), W, H,
+             float(s.tanfovx), float(s.tanfovy), 0, 1, ptr(records), ptr(radii), None, ptr(keys), None, ptr(sort_vals),
+             ptr(totals), None, None, dgr._stream())
+    n, e1, e2, v = (int(x) for x in totals[:4].tolist())
+    assert (n, v) == (N, V) and int(totals[4]) == 0
+    tiles = ((W + 15) // 16) * ((H + 15) // 16)
+
+    def build(V_, N_, E1_, E2_, error_value):
+        nb = lib.gsr_bin_lists_bytes(V_, E1_, E2_, W, H)
+        scratch = torch.empty((nb,), dtype=torch.uint8, device="cuda")
+        pad = 1024
+        plist = torch.full((N_ + 2 * pad,), 0x5A5A5A5A, **u32)
+        ranges = torch.full((2 * tiles + 2 * pad,), 0x5A5A5A5A, **u32)
+        err = torch.tensor([error_value], **u32)
+        status = torch.zeros((1,), **u32)
+        dgr._run("bin_lists", lib.gsr_bin_lists, P, V_, N_, E1_, E2_, W, H, ptr(st.sorted_vals), ptr(plist[pad:]),
+                 ptr(ranges[pad:]), None, ptr(err), ptr(totals), ptr(status), ptr(scratch), nb, dgr._stream())
+        torch.cuda.synchronize()
+        for buf in (plist, ranges):
+            assert bool((buf[:pad] == 0x5A5A5A5A).all()) and bool((buf[-pad:] == 0x5A5A5A5A).all())
+        return plist[pad:pad + N_], ranges[pad:pad + 2 * tiles].reshape(tiles, 2), int(status[0])
+
+    plist, ranges, status = build(v, n, e1, e2, 0)
+    assert status == 0 and torch.equal(plist, st.point_list) and torch.equal(ranges, st.ranges)
+    plist, ranges, status = build(v, n, e1, e2, 4)                       # "pass 2 gave up"
+    assert status == dgr.STATUS_SORT and int(ranges.abs().sum()) == 0
+    assert bool((plist == 0x5A5A5A5A).all())                             # no list written at all
+    plist, ranges, status = build(v - 1, n - 1, e1 - 1, e2 - 1, 0)       # somebody else's sizes (smaller buffers)
+    assert status == dgr.STATUS_TOTALS and int(ranges.abs().sum()) == 0
+    assert bool((plist == 0x5A5A5A5A).all())
+    plist, ranges, status = build(v, n + 5, e1, e2, 1)
+    assert status == (dgr.STATUS_SORT | dgr.STATUS_TOTALS)
+
+
+def test_a_sort_that_gives_up_in_release_mode_surfaces_at_the_next_forward():
+    """debug=False: nobody waits for the sort's status.  With a patience of one look-back step the 1M-key
+    sort of this scene (almost certainly) gives up; the forward then renders the background, and the
+    NEXT forward on this thread raises RasterizerFault from the read-back it does anyway.  After that
+    the status is clear and rendering works again."""
+    import diff_gaussian_rasterization as dgr
+    cloud, cam, bg, _ = make_scene(1_000_000, 640, 360, sh_degree=0, seed=6, bg=(0.25, 0.5, 0.75), coeffs=1)
+    s = _gpu_settings(cam, bg, 0, 1.0)
+    c = cloud.to("cuda")
+    good = _forward(dgr, s, c)
+    torch.cuda.synchronize()
+    dgr._lib.gsr_debug_sort_spin_limit(1)
+    try:
+        shaky = _forward(dgr, s, c)
+        torch.cuda.synchronize()
+    finally:
+        dgr._lib.gsr_debug_sort_spin_limit(0)
+    status = int(dgr._status_word(c.xyz.device)[0])
+    print("status after the impatient sort:", status, flush=True)
+    if status == 0:
+        assert torch.equal(shaky.color, good.color)                      # no workgroup happened to wait
+        again = _forward(dgr, s, c)
+    else:
+        assert status == dgr.STATUS_SORT
+        want = bg.cuda()[:, None, None].expand_as(shaky.color)
+        assert torch.equal(shaky.color, want) and int(shaky.n_contrib.sum()) == 0
+        g = dgr.rasterize_backward(s, shaky, torch.ones_like(shaky.color), c.xyz, shs=c.features, scales=c.scaling,
+                                   rotations=c.rotation)
+        assert all(float(v.abs().max()) == 0.0 for v in g.values() if v is not None)
+        with pytest.raises(dgr.RasterizerFault, match="GSR_E_SORT"):
+            _forward(dgr, s, c)
+        assert int(dgr._status_word(c.xyz.device)[0]) == 0
+        again = _forward(dgr, s, c)
+    torch.cuda.synchronize()
+    assert torch.equal(again.color, good.color) and torch.equal(again.point_list, good.point_list)

@@ -114,6 +114,8 @@ def _arena_worker(rank, world, port, q):
     for k in params:
         assert torch.equal(separate[k].grad, params[k].grad)     # per-tensor collectives give the same sums
     q.put((rank, scale, {k: (p.grad * scale).clone() for k, p in params.items()}))
+    # losses already normalised over all ranks' views: the sum is the gradient, nothing left to scale
+    assert all_reduce_gradients({}, average=False) == 1.0 and all_reduce_gradients({}) == 0.5
     dist.barrier()
     dist.destroy_process_group()
 
