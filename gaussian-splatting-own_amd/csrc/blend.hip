@@ -225,12 +225,38 @@ __global__ void __launch_bounds__(256) blend_fwd_kernel(int W, int H, const uint
 // ---------------------------------------------------------------------------
 // backward
 // ---------------------------------------------------------------------------
-// The backward's reduction scratch holds 8 rows of 64 lane values per wave.  Odd rows are stored
-// rotated by 32 words: the 16-byte reads of blend_bwd_kernel (lane 8k+s reads words 4s..4s+3 and
-// 32+4s..32+4s+3 of row k) then touch 64 distinct banks in each of ds_read_b128's four groups of 16
-// lanes (rows 2m and 2m+1 would otherwise meet in the same 32 banks) without any padding between
-// the rows, and LDS is what limits how many workgroups a CU holds.
+// The backward's reduction scratch holds 8 rows of 64 lane values per wave, lane l's value of row k
+// at word 64 k + l, with no padding between the rows (LDS is what limits how many workgroups a CU
+// holds).  Lane 8k+s of blend_bwd_kernel reads words 4s..4s+3 and 32+4s..32+4s+3 of row k with two
+// 16-byte loads; the lanes of rows 2, 3, 6, 7 take the two halves in the other order, which keeps
+// each of ds_read_b128's four groups of 16 lanes on 64 distinct banks (rows 2m and 2m+1 would
+// otherwise meet in the same 32 banks).
 constexpr int kRedStride = 64;
+
+// Stores v0..v7 as rows 0..7 of the wave's reduction scratch at LDS byte offset `base` (wave-uniform)
+// with ds_write_addtid_b32: address = M0 + offset + 4 * lane.  The instruction takes no address
+// register, so it moves half as many registers to the LDS as ds_write_b32 does, and that transfer, not
+// the LDS array, is what a 4-byte store costs (blend_bwd_kernel 0.325 -> 0.315 ms at 1M Gaussians).
+// One wait state between the write of M0 and its use.  The scratch is written here only: the
+// "memory" clobber orders the stores against the loads around them, and `base` carries the
+// scratch's address into the statement, so the compiler has to assume it is written.
+__device__ __forceinline__ void store_rows_addtid(unsigned base, float v0, float v1, float v2, float v3, float v4,
+                                                  float v5, float v6, float v7) {
+  asm volatile(
+      "s_mov_b32 m0, %8\n\t"
+      "s_nop 0\n\t"
+      "ds_write_addtid_b32 %0 offset:0\n\t"
+      "ds_write_addtid_b32 %1 offset:256\n\t"
+      "ds_write_addtid_b32 %2 offset:512\n\t"
+      "ds_write_addtid_b32 %3 offset:768\n\t"
+      "ds_write_addtid_b32 %4 offset:1024\n\t"
+      "ds_write_addtid_b32 %5 offset:1280\n\t"
+      "ds_write_addtid_b32 %6 offset:1536\n\t"
+      "ds_write_addtid_b32 %7 offset:1792"
+      :
+      : "v"(v0), "v"(v1), "v"(v2), "v"(v3), "v"(v4), "v"(v5), "v"(v6), "v"(v7), "s"(base)
+      : "m0", "memory");
+}
 
 template <int CTRL>
 __device__ __forceinline__ float dpp_add(float v) {
@@ -288,12 +314,12 @@ __global__ void __launch_bounds__(256) blend_bwd_kernel(int W, int H, const uint
   // acc = colour composited behind the current splat (everything already visited in this
   // back-to-front walk), per channel.
   float T = Tf, acc0 = 0.f, acc1 = 0.f, acc2 = 0.f;
-  // where this lane writes its value of an even / odd row, and where it reads its two quarters of row lane/8
-  float* const red_even = s_red[wave] + lane;
-  float* const red_odd = s_red[wave] + ((lane + 32) & 63);
-  const int my_row = lane >> 3, my_rot = 32 * (my_row & 1), my_seg = 4 * (lane & 7);
-  const float4* const red_lo = reinterpret_cast<const float4*>(s_red[wave] + my_row * kRedStride + ((my_seg + my_rot) & 63));
-  const float4* const red_hi = reinterpret_cast<const float4*>(s_red[wave] + my_row * kRedStride + ((my_seg + 32 + my_rot) & 63));
+  // the wave's reduction scratch: its LDS byte offset for the stores, and where this lane reads its two quarters of row lane/8
+  typedef __attribute__((address_space(3))) float lds_float;
+  const unsigned red_base = __builtin_amdgcn_readfirstlane((unsigned)(uintptr_t)(lds_float*)s_red[wave]);
+  const int my_row = lane >> 3, my_first = (my_row & 2) ? 32 : 0, my_seg = 4 * (lane & 7);
+  const float4* const red_lo = reinterpret_cast<const float4*>(s_red[wave] + my_row * kRedStride + my_first + my_seg);
+  const float4* const red_hi = reinterpret_cast<const float4*>(s_red[wave] + my_row * kRedStride + (my_first ^ 32) + my_seg);
 
   for (int b = (tile_last - 1) / kBatch; b >= 0; b--) {
     __syncthreads();
@@ -356,20 +382,13 @@ __global__ void __launch_bounds__(256) blend_bwd_kernel(int W, int H, const uint
         const float ux = u * dx, uy = u * dy;
         // Nine sums over the wave's 64 lanes.  Cross-lane VALU operations (DPP) are the expensive
         // way to do this on gfx950 (36 of them cost as much as the rest of the loop), so the sums
-        // are transposed through LDS instead: every lane stores its nine values as columns
+        // are transposed through LDS instead: every lane stores eight of its values as columns
         // (conflict-free), then lane 8k+s adds up eight elements of row k, fetched with two 16-byte
-        // reads (conflict-free for the row layout chosen above), and three DPP steps combine the
+        // reads (conflict-free in the order chosen above), and three DPP steps combine the
         // eight lanes of a row.  The ninth sum stays in registers: four DPP steps within the rows of
         // 16 lanes, two lane-permute swaps across them.  A wave's LDS operations execute in order, so
         // no barrier is needed.
-        red_even[0 * kRedStride] = u;
-        red_odd[1 * kRedStride] = ux;
-        red_even[2 * kRedStride] = uy;
-        red_odd[3 * kRedStride] = ux * dx;
-        red_even[4 * kRedStride] = ux * dy;
-        red_odd[5 * kRedStride] = uy * dy;
-        red_even[6 * kRedStride] = dch * dp0;
-        red_odd[7 * kRedStride] = dch * dp1;
+        store_rows_addtid(red_base, u, ux, uy, ux * dx, ux * dy, uy * dy, dch * dp0, dch * dp1);
         const float4 a0 = *red_lo, a1 = *red_hi;
         float v = ((a0.x + a0.y) + (a0.z + a0.w)) + ((a1.x + a1.y) + (a1.z + a1.w));
         float v8 = dch * dp2;

@@ -380,14 +380,21 @@ def rasterize_forward(s: GaussianRasterizationSettings, means3D, opacities, shs=
 
         # The blend backward accumulates into a zeroed (P,16) buffer.  The depth sort and the
         # partitions are short dependent launches that leave HBM idle: the fill runs beside them on
-        # a second stream.
+        # a second stream.  The buffer itself comes from the caller's stream like every other tensor
+        # here (a block handed out on the side stream and marked as used by this one would make the
+        # caching allocator poll events, and fall back to hipMalloc whenever a long backward has not
+        # finished by the next forward); the two events order the fill after the block's previous use
+        # and before its next one.
         if prepare_backward and _OVERLAP:
             main, side = torch.cuda.current_stream(dev), _side_stream(dev)
+            st.dsplat = torch.empty((P, GRAD_WORDS), dtype=torch.float32, device=dev)
+            handed_out = torch.cuda.Event()
+            handed_out.record(main)
+            side.wait_event(handed_out)
             with torch.cuda.stream(side):
-                st.dsplat = torch.zeros((P, GRAD_WORDS), dtype=torch.float32, device=dev)
+                st.dsplat.zero_()
                 cleared = torch.cuda.Event()
                 cleared.record(side)
-            st.dsplat.record_stream(main)
 
         # The list sizes go to the host (the pipeline's one read-back) while the GPU sorts by depth:
         # the copy is queued before the sort and the host waits for the copy alone.
