@@ -24,6 +24,7 @@
 // so every workgroup it waits for is already running or done; the waits are bounded by a spin
 // limit anyway (on overrun the sort sets an error word and still terminates).
 #include <atomic>
+#include <mutex>
 
 #include "gsr_common.h"
 
@@ -420,3 +421,61 @@ const uint32_t* depth_sort_error_word(const void* scratch) { return (const uint3
 void set_sort_spin_limit(uint32_t limit) { g_spin_limit.store(limit ? limit : kSpinLimit, std::memory_order_relaxed); }
 
 }  // namespace gsr
+
+// ---------------------------------------------------------------------------
+// The depth sort for callers that cannot allocate: its scratch is a device array of the library
+// ---------------------------------------------------------------------------
+namespace {
+
+constexpr int kStaticMaxKeys = 1 << 20;
+// what layout(kStaticMaxKeys) asks for: look-back words and histograms (1.1 MB) + two key and two value buffers
+constexpr size_t kStaticBytes = 26284288;
+
+// Every GPU the library runs on holds its own copy of this array, at its own address, until the process ends.
+static __device__ __align__(256) unsigned char scratch[kStaticBytes];
+
+constexpr int kMaxDevices = 64;
+std::mutex g_static_mutex;
+void* g_static_ptr[kMaxDevices];          // the array's address on each device, looked up once per device
+
+// The device address of `scratch` on the current device.  Host code never uses the array's name for its
+// memory: the name is a host-side stand-in, the address comes from the runtime.
+int static_scratch(void** out) {
+  int dev = -1;
+  hipError_t e = hipGetDevice(&dev);
+  if (e != hipSuccess) return gsr::fail(GSR_E_LAUNCH, "bin_sort_static: hipGetDevice: %s", hipGetErrorString(e));
+  if (dev < 0 || dev >= kMaxDevices) return gsr::fail(GSR_E_INVALID, "bin_sort_static: device %d out of range", dev);
+  std::lock_guard<std::mutex> lock(g_static_mutex);
+  if (!g_static_ptr[dev]) {
+    void* ptr = nullptr;
+    e = hipGetSymbolAddress((void**)&ptr, HIP_SYMBOL(scratch));
+    if (e != hipSuccess || !ptr)
+      return gsr::fail(GSR_E_LAUNCH, "bin_sort_static: hipGetSymbolAddress: %s", hipGetErrorString(e));
+    if ((uintptr_t)ptr & 255) return gsr::fail(GSR_E_SCRATCH, "bin_sort_static: the static scratch is not 256-byte aligned");
+    g_static_ptr[dev] = ptr;
+  }
+  *out = g_static_ptr[dev];
+  return GSR_OK;
+}
+
+}  // namespace
+
+extern "C" int gsr_bin_sort_static(int P, const uint32_t* depth_keys, const uint64_t* sort_vals, uint64_t* sorted_vals,
+                                   const uint32_t** error_word, void* stream) {
+  GSR_REQUIRE(P >= 0, "bin_sort_static: bad P");
+  if (P > kStaticMaxKeys)
+    return gsr::fail(GSR_E_TOO_LARGE, "bin_sort_static: %d keys exceed the static scratch's capacity of %d; use gsr_bin_sort "
+                     "with caller memory", P, kStaticMaxKeys);
+  if (layout((uint32_t)kStaticMaxKeys).total > kStaticBytes)
+    return gsr::fail(GSR_E_SCRATCH, "bin_sort_static: the static scratch (%zu bytes) is smaller than the sort's layout (%zu)",
+                     kStaticBytes, layout((uint32_t)kStaticMaxKeys).total);
+  void* ptr = nullptr;
+  int rc = static_scratch(&ptr);
+  if (rc) return rc;
+  if (error_word) *error_word = gsr::depth_sort_error_word(ptr);
+  if (P == 0) return GSR_OK;
+  GSR_REQUIRE(depth_keys && sort_vals && sorted_vals, "bin_sort_static: null pointer");
+  // depth_sort clears the look-back words, tickets, histograms and the error word with a kernel of its own
+  // before it uses them: whatever the previous call left in the array does not matter
+  return gsr::depth_sort(P, depth_keys, sort_vals, sorted_vals, ptr, (hipStream_t)stream);
+}

@@ -182,6 +182,22 @@ int gsr_bin_sort_status(int P, const void* scratch, size_t scratch_bytes, void* 
 const uint32_t* gsr_bin_sort_error_word(const void* sort_scratch);
 void gsr_debug_sort_spin_limit(uint32_t limit);
 
+/* gsr_bin_sort_static: gsr_bin_sort for callers that cannot allocate device memory or have
+ * none to hand in (code under HIP graph capture, tight serving loops, harnesses that forbid
+ * hipMalloc).  It has no counterpart in the reference.  The sort's scratch is a 26,284,288-byte
+ * device array inside the library (every GPU the library runs on holds its own copy until the
+ * process ends), so P is limited to GSR_BIN_SORT_STATIC_MAX = 2^20 keys: more is refused with
+ * GSR_E_TOO_LARGE.  The call allocates nothing (no hipMalloc / hipFree, no allocating library
+ * routine), on any call; it only enqueues kernels on `stream`, whose device must be current.
+ * Same result as gsr_bin_sort, bit for bit.  *error_word (optional out, may be NULL) receives the
+ * device address of the sort's error word, for gsr_bin_lists' sort_error argument.
+ * All calls on one GPU share that GPU's array: calls that overlap in time on one GPU (two streams,
+ * two threads) race and give undefined results; calls that follow each other on one stream are fine,
+ * each clears what it needs to start from zero. */
+#define GSR_BIN_SORT_STATIC_MAX (1 << 20)
+int gsr_bin_sort_static(int P, const uint32_t* depth_keys, const uint64_t* sort_vals,
+                        uint64_t* sorted_vals, const uint32_t** error_word, void* stream);
+
 /* gsr_bin_lists: point_list (N) uint32 = Gaussian index per sorted instance;
  * ranges (tiles,2) uint32 = [start,end) into point_list per tile, (0,0) for
  * empty tiles.
