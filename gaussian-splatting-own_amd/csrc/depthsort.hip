@@ -12,6 +12,10 @@
 //  * all per-pass state (look-back words, workgroup tickets, histograms) is cleared by ONE
 //    launch for the whole sort, and the bin scan runs inside the pass kernels:
 //    6 launches per sort instead of 15;
+//  * depth keys are IEEE floats: when every visible Gaussian lies within one factor of 4 of depth
+//    (z in [2, 8) for a camera four units from a unit-sized scene) their top bytes are all equal
+//    and the fourth pass would be the identity.  The histograms say so up front: the third pass then
+//    writes the final result and the fourth returns at once;
 //  * the look-back is two-level and windowed: a workgroup sums the counts of the (at most 15)
 //    earlier workgroups of its group of 16 with all loads in flight together, the last workgroup
 //    of a group publishes the group's count and later its inclusive prefix, and everybody looks
@@ -121,6 +125,7 @@ struct PassArgs {
   const u64* vals_in;
   uint32_t* keys_out;     // unused by the last pass
   u64* vals_out;
+  u64* final_out;         // passes 2 and 3: the sort's result (sorted_vals)
   const uint32_t* hist;   // this pass's 256 bins
   uint32_t* ctl;
   uint32_t* states;       // [workgroup][256] look-back words of this pass
@@ -187,6 +192,20 @@ __global__ void __launch_bounds__(kThreads) sort_pass_kernel(PassArgs a) {
   // against the up-front histograms, and its positions would no longer be bounded by the key count:
   // the failure is sticky, every later pass of the sort does nothing (one scalar load, uniform).
   if (PASS > 0 && a.ctl[kCtlError] != 0u) return;
+
+  // One bin of the top byte's histogram holds every key: the last pass would move nothing.  Pass 2 then
+  // writes the result itself and pass 3 has nothing to do.  The test reads this pass's view of the
+  // top-byte histogram (hist + 256 for pass 2, hist for pass 3) against the number of valid keys;
+  // every workgroup of both kernels comes to the same answer.
+  bool top_byte_is_constant = false;
+  if (PASS >= 2) {
+    const uint32_t* top = PASS == 2 ? a.hist + 256 : a.hist;
+    const uint32_t all = a.ctl[kCtlValid];
+    top_byte_is_constant = __syncthreads_or(threadIdx.x < 256 && all != 0u && top[threadIdx.x & 255] == all) != 0;
+    if (PASS == 3 && top_byte_is_constant) return;
+  }
+  const bool writes_result = PASS == 3 || (PASS == 2 && top_byte_is_constant);
+  u64* const vals_dst = writes_result ? a.final_out : a.vals_out;
 
   if (tid == 0) s_misc[0] = atomicAdd(&a.ctl[kCtlTicket + PASS], 1u);
   if (tid < 256) s_total[tid] = 0u;
@@ -324,8 +343,8 @@ __global__ void __launch_bounds__(kThreads) sort_pass_kernel(PassArgs a) {
       const uint32_t kk = s_keys[r];
       const uint32_t dst = s_dest[(kk >> kShift) & 255u] + r;
       if (dst < a.P) {     // always true in a healthy sort; holds the stores inside the buffers whatever a failed look-back returned
-        if (PASS < 3) a.keys_out[dst] = kk;
-        a.vals_out[dst] = s_vals[r];
+        if (!writes_result) a.keys_out[dst] = kk;
+        vals_dst[dst] = s_vals[r];
       }
     }
   }
@@ -383,18 +402,18 @@ int depth_sort(int P, const uint32_t* keys, const uint64_t* vals, uint64_t* sort
   const size_t per_pass = L.state_words + L.group_words;
   auto args = [&](int pass, const uint32_t* kin, const u64* vin, uint32_t* kout, u64* vout) {
     uint32_t* s = states + pass * per_pass;
-    return PassArgs{kin, vin, kout, vout, hist + 256 * pass, ctl, s, s + L.state_words, (uint32_t)P, spin_limit};
+    return PassArgs{kin, vin, kout, vout, (u64*)sorted_vals, hist + 256 * pass, ctl, s, s + L.state_words, (uint32_t)P, spin_limit};
   };
   if ((uint32_t)P >= kManyFrom) {
     hipLaunchKernelGGL((sort_pass_kernel<0, kManyItems>), grid, block, 0, st, args(0, keys, (const u64*)vals, ka, va));
     hipLaunchKernelGGL((sort_pass_kernel<1, kManyItems>), grid, block, 0, st, args(1, ka, va, kb, vb));
     hipLaunchKernelGGL((sort_pass_kernel<2, kManyItems>), grid, block, 0, st, args(2, kb, vb, ka, va));
-    hipLaunchKernelGGL((sort_pass_kernel<3, kManyItems>), grid, block, 0, st, args(3, ka, va, nullptr, (u64*)sorted_vals));
+    hipLaunchKernelGGL((sort_pass_kernel<3, kManyItems>), grid, block, 0, st, args(3, ka, va, nullptr, nullptr));
   } else {
     hipLaunchKernelGGL((sort_pass_kernel<0, kFewItems>), grid, block, 0, st, args(0, keys, (const u64*)vals, ka, va));
     hipLaunchKernelGGL((sort_pass_kernel<1, kFewItems>), grid, block, 0, st, args(1, ka, va, kb, vb));
     hipLaunchKernelGGL((sort_pass_kernel<2, kFewItems>), grid, block, 0, st, args(2, kb, vb, ka, va));
-    hipLaunchKernelGGL((sort_pass_kernel<3, kFewItems>), grid, block, 0, st, args(3, ka, va, nullptr, (u64*)sorted_vals));
+    hipLaunchKernelGGL((sort_pass_kernel<3, kFewItems>), grid, block, 0, st, args(3, ka, va, nullptr, nullptr));
   }
   return gsr::check_launch("depth_sort");
 }

@@ -1,0 +1,133 @@
+// The whole forward in one call: preprocess -> list sizes to the host -> depth sort -> tile lists -> blend.
+// The shape of the replaced module's own native entry (one call per render, memory for the lists obtained
+// through a callback once their size is known); built from the stage entry points of gsr.h, so the results
+// are theirs bit for bit.  The point of it is the host side: one transition into native code per render
+// instead of five, and one workspace instead of a dozen buffers, which is what a render of 100k
+// Gaussians spends as much time on as on its kernels.
+#include "gsr_common.h"
+
+namespace {
+
+struct Carve {
+  char* base;
+  size_t at = 0;
+  explicit Carve(void* p) : base((char*)p) {}
+  template <typename T> T* take(size_t bytes) {
+    T* p = base ? (T*)(base + at) : nullptr;
+    at += gsr::align_up(bytes ? bytes : 1, 256);
+    return p;
+  }
+};
+
+struct Workspace {
+  uint32_t* records; uint32_t* depth_keys; uint64_t* sort_vals; uint64_t* sorted_vals; uint32_t* totals;
+  void* sort_scratch; size_t sort_bytes; uint32_t* ranges; float* final_T; uint32_t* n_contrib; size_t total;
+};
+
+Workspace carve(void* base, int P, int W, int H) {
+  Carve c(base);
+  Workspace w;
+  const size_t p = (size_t)(P > 0 ? P : 0), tiles = (size_t)gsr::div_up(W, GSR_TILE_X) * gsr::div_up(H, GSR_TILE_Y);
+  w.records = c.take<uint32_t>(p * GSR_REC_WORDS * 4);
+  w.depth_keys = c.take<uint32_t>(p * 4);
+  w.sort_vals = c.take<uint64_t>(p * 8);
+  w.sorted_vals = c.take<uint64_t>(p * 8);
+  w.totals = c.take<uint32_t>(gsr_totals_words(P) * 4);
+  w.sort_bytes = gsr_bin_sort_bytes(P);
+  w.sort_scratch = c.take<char>(w.sort_bytes);
+  w.ranges = c.take<uint32_t>(tiles * 8);
+  w.final_T = c.take<float>((size_t)W * H * 4);
+  w.n_contrib = c.take<uint32_t>((size_t)W * H * 4);
+  w.total = c.at;
+  return w;
+}
+
+int hip_fail(const char* what, hipError_t e) { return gsr::fail(GSR_E_LAUNCH, "forward: %s: %s", what, hipGetErrorString(e)); }
+
+}  // namespace
+
+extern "C" size_t gsr_forward_workspace_bytes(int P, int W, int H) {
+  if (P < 0 || W <= 0 || H <= 0) return 0;
+  return carve(nullptr, P, W, H).total;
+}
+
+extern "C" int gsr_forward(const GsrForwardArgs* a, gsr_resize_fn resize, void* resize_ctx, GsrForwardOut* out,
+                           void* stream) {
+  GSR_REQUIRE(a && out && resize, "forward: null argument");
+  GSR_REQUIRE(a->P >= 0 && a->W > 0 && a->H > 0, "forward: bad sizes P=%d W=%d H=%d", a->P, a->W, a->H);
+  GSR_REQUIRE(a->bg && a->out_color && a->radii, "forward: null pointer");
+  GSR_REQUIRE(a->workspace && ((uintptr_t)a->workspace & 255) == 0, "forward: workspace must be non-null and 256-byte aligned");
+  GSR_REQUIRE(a->P == 0 || (a->h_totals && a->event), "forward: the landing buffer and its event are required");
+  const int P = a->P, W = a->W, H = a->H;
+  const Workspace w = carve(a->workspace, P, W, H);
+  if (a->workspace_bytes < w.total)
+    return gsr::fail(GSR_E_SCRATCH, "forward: workspace too small (%zu < %zu)", a->workspace_bytes, w.total);
+  hipStream_t st = (hipStream_t)stream;
+  *out = GsrForwardOut{};
+  out->records = w.records; out->depth_keys = w.depth_keys; out->sorted_vals = w.sorted_vals; out->ranges = w.ranges;
+  out->final_T = w.final_T; out->n_contrib = w.n_contrib;
+  auto checkpoint = [&](const char* what) -> int {      // debug mode: wait and look for errors after every stage
+    if (!a->debug) return GSR_OK;
+    const hipError_t e = hipStreamSynchronize(st);
+    return e == hipSuccess ? GSR_OK : hip_fail(what, e);
+  };
+
+  uint32_t N = 0, E1 = 0, E2 = 0, V = 0;
+  const uint32_t* sort_error = nullptr;
+  if (P > 0) {
+    int rc;
+    if (a->raw)
+      rc = gsr_preprocess_fwd_raw(P, a->D, a->M - 1, a->means3D, a->scales, a->scale_modifier, a->rotations, a->opacities,
+                                  a->shs, a->shs_rest, a->viewmatrix, a->projmatrix, a->campos, W, H, a->tanfovx,
+                                  a->tanfovy, a->reference_lists, w.records, a->radii, nullptr, w.depth_keys, nullptr,
+                                  w.sort_vals, w.totals, a->status, a->visible, stream);
+    else
+      rc = gsr_preprocess_fwd(P, a->D, a->M, a->means3D, a->scales, a->scale_modifier, a->rotations, a->opacities, a->shs,
+                              a->colors_precomp, a->cov3D_precomp, a->viewmatrix, a->projmatrix, a->campos, W, H,
+                              a->tanfovx, a->tanfovy, a->prefiltered, a->reference_lists, w.records, a->radii, nullptr,
+                              w.depth_keys, nullptr, w.sort_vals, w.totals, a->status, a->visible, stream);
+    if (rc) return rc;
+    if ((rc = checkpoint("preprocess"))) return rc;
+    // the list sizes (and the carried status word) travel to the host while the GPU sorts by depth
+    hipError_t e = hipMemcpyAsync(a->h_totals, w.totals, 8 * sizeof(uint32_t), hipMemcpyDeviceToHost, st);
+    if (e == hipSuccess) e = hipEventRecord((hipEvent_t)a->event, st);
+    if (e != hipSuccess) return hip_fail("read-back of the list sizes", e);
+    rc = gsr_bin_sort(P, w.depth_keys, w.sort_vals, w.sorted_vals, w.sort_scratch, w.sort_bytes, stream);
+    if (rc) return rc;
+    sort_error = gsr_bin_sort_error_word(w.sort_scratch);
+    if (a->debug && (rc = gsr_bin_sort_status(P, w.sort_scratch, w.sort_bytes, stream))) return rc;
+    e = hipEventSynchronize((hipEvent_t)a->event);
+    if (e != hipSuccess) return hip_fail("waiting for the list sizes", e);
+    N = a->h_totals[0]; E1 = a->h_totals[1]; E2 = a->h_totals[2]; V = a->h_totals[3];
+    out->carried_status = a->h_totals[4];
+    if (out->carried_status)
+      return gsr::fail(GSR_E_EARLIER, "forward: an earlier forward on this status word built no tile lists (status 0x%x)",
+                       out->carried_status);
+  }
+  out->N = N; out->E1 = E1; out->E2 = E2; out->V = V;
+
+  const size_t lists_bytes = gsr_bin_lists_bytes(V, E1, E2, W, H);
+  const size_t list_words = N > 0 ? N : 1;
+  // point_list | (tile ids) | scratch of the list builder, as one request
+  Carve need(nullptr);
+  need.take<uint32_t>(list_words * 4);
+  if (a->keep_tile_ids) need.take<uint32_t>(list_words * 4);
+  need.take<char>(lists_bytes);
+  void* mem = resize(resize_ctx, need.at);
+  if (!mem || ((uintptr_t)mem & 255))
+    return gsr::fail(GSR_E_SCRATCH, "forward: the resize callback returned %s for %zu bytes", mem ? "misaligned memory" : "nothing",
+                     need.at);
+  Carve got(mem);
+  out->point_list = got.take<uint32_t>(list_words * 4);
+  out->tile_ids_sorted = a->keep_tile_ids ? got.take<uint32_t>(list_words * 4) : nullptr;
+  void* lists_scratch = got.take<char>(lists_bytes);
+  int rc = gsr_bin_lists(P, V, N, E1, E2, W, H, w.sorted_vals, out->point_list, w.ranges, out->tile_ids_sorted, sort_error,
+                         P > 0 ? w.totals : nullptr, a->status, lists_scratch, lists_bytes, stream);
+  if (rc) return rc;
+  if ((rc = checkpoint("bin_lists"))) return rc;
+  if (a->before_blend) a->before_blend(a->before_blend_ctx);
+  rc = gsr_blend_fwd_timed(W, H, w.ranges, out->point_list, w.records, a->bg, a->out_color, w.final_T, w.n_contrib,
+                           a->blend_start_event, a->blend_stop_event, stream);
+  if (rc) return rc;
+  return checkpoint("blend");
+}

@@ -41,6 +41,40 @@ GRAD_WORDS = 16
 REFERENCE_LISTS = os.environ.get("GSR_SHORT_LISTS", "0") in ("", "0")
 # GSR_NO_OVERLAP=1 clears the backward's accumulator on the caller's stream (A/B runs, debugging)
 _OVERLAP = os.environ.get("GSR_NO_OVERLAP", "0") in ("", "0")
+# The forward is ONE call into the library (gsr_forward) unless GSR_STAGED=1 or a stage timer is installed;
+# then it is the sequence of stage calls, with the same results bit for bit.
+SINGLE_CALL = os.environ.get("GSR_STAGED", "0") in ("", "0")
+
+
+class _ForwardArgs(C.Structure):
+    """GsrForwardArgs of gsr.h."""
+    _fields_ = [("P", C.c_int), ("D", C.c_int), ("M", C.c_int), ("raw", C.c_int),
+                ("means3D", C.c_void_p), ("scales", C.c_void_p), ("rotations", C.c_void_p), ("opacities", C.c_void_p),
+                ("shs", C.c_void_p), ("shs_rest", C.c_void_p), ("colors_precomp", C.c_void_p),
+                ("cov3D_precomp", C.c_void_p), ("viewmatrix", C.c_void_p), ("projmatrix", C.c_void_p),
+                ("campos", C.c_void_p), ("bg", C.c_void_p),
+                ("scale_modifier", C.c_float), ("tanfovx", C.c_float), ("tanfovy", C.c_float),
+                ("W", C.c_int), ("H", C.c_int), ("prefiltered", C.c_int), ("reference_lists", C.c_int),
+                ("debug", C.c_int), ("keep_tile_ids", C.c_int),
+                ("out_color", C.c_void_p), ("radii", C.c_void_p), ("visible", C.c_void_p),
+                ("workspace", C.c_void_p), ("workspace_bytes", C.c_size_t),
+                ("h_totals", C.c_void_p), ("event", C.c_void_p), ("status", C.c_void_p),
+                ("before_blend", C.c_void_p), ("before_blend_ctx", C.c_void_p),
+                ("blend_start_event", C.c_void_p), ("blend_stop_event", C.c_void_p)]
+
+
+class _ForwardOut(C.Structure):
+    """GsrForwardOut of gsr.h."""
+    _fields_ = [("N", C.c_uint32), ("V", C.c_uint32), ("E1", C.c_uint32), ("E2", C.c_uint32),
+                ("carried_status", C.c_uint32),
+                ("records", C.c_void_p), ("depth_keys", C.c_void_p), ("sorted_vals", C.c_void_p),
+                ("ranges", C.c_void_p), ("final_T", C.c_void_p), ("n_contrib", C.c_void_p),
+                ("point_list", C.c_void_p), ("tile_ids_sorted", C.c_void_p)]
+
+
+_RESIZE_FN = C.CFUNCTYPE(C.c_void_p, C.c_void_p, C.c_size_t)
+_HOOK_FN = C.CFUNCTYPE(None, C.c_void_p)
+GSR_E_EARLIER = -6
 
 
 def _load():
@@ -79,6 +113,9 @@ def _load():
                                        vp, vp, vp, vp, vp, vp, vp, vp, vp]
     lib.gsr_preprocess_fwd_raw.argtypes = [ci, ci, ci, vp, vp, cf, vp, vp, vp, vp, vp, vp, vp, ci, ci, cf, cf, ci,
                                            vp, vp, vp, vp, vp, vp, vp, vp, vp, vp]
+    lib.gsr_forward_workspace_bytes.restype = C.c_size_t
+    lib.gsr_forward_workspace_bytes.argtypes = [ci, ci, ci]
+    lib.gsr_forward.argtypes = [C.POINTER(_ForwardArgs), _RESIZE_FN, vp, C.POINTER(_ForwardOut), vp]
     lib.gsr_preprocess_bwd_raw.argtypes = [ci, ci, ci, vp, vp, cf, vp, vp, vp, vp, vp, vp, vp, ci, ci, cf, cf,
                                            vp, vp, vp, vp, vp, vp, vp, vp, vp, vp]
     return lib
@@ -319,17 +356,119 @@ class ForwardState:
         return (self.tile_ids_sorted.to(torch.int64) << 32) | d
 
 
+def _read_back_event(dev: torch.device):
+    """The event a single-call forward marks its read-back with, one per (host thread, device)."""
+    d = _per_device(dev)
+    if "event" not in d:
+        d["event"] = _lib.gsr_event_create()
+        if not d["event"]:
+            raise RuntimeError("libgsr_hip: " + _lib.gsr_last_error().decode())
+    return d["event"]
+
+
+def _forward_single_call(s, st, dev, means3D, opacities, shs, colors_precomp, scales, rotations, cov3D_precomp,
+                         keep_tile_ids, raw, prepare_backward, ref_lists) -> None:
+    """gsr_forward: fills ``st`` like the staged path does.  Everything but the user-visible outputs lives in
+    one workspace tensor; the tile lists come from the resize callback."""
+    P, W, H = st.P, st.W, st.H
+    u8 = dict(dtype=torch.uint8, device=dev)
+    st.radii = torch.empty((P,), dtype=torch.int32, device=dev)
+    st.visible = torch.empty((P,), dtype=torch.bool, device=dev)
+    st.color = torch.empty((3, H, W), dtype=torch.float32, device=dev)
+    nbytes = _lib.gsr_forward_workspace_bytes(P, W, H)
+    ws = torch.empty((nbytes,), **u8)
+    keep = {}
+
+    def resize(_ctx, bytes_):
+        keep["lists"] = torch.empty((bytes_,), **u8)
+        return keep["lists"].data_ptr()
+
+    hook = None
+    if prepare_backward and _OVERLAP and P > 0:
+        # the accumulator of the blend backward is cleared on a second stream while this one runs the forward
+        main, side = torch.cuda.current_stream(dev), _side_stream(dev)
+        st.dsplat = torch.empty((P, GRAD_WORDS), dtype=torch.float32, device=dev)
+        handed_out = torch.cuda.Event()
+        handed_out.record(main)
+        side.wait_event(handed_out)
+        with torch.cuda.stream(side):
+            st.dsplat.zero_()
+            cleared = torch.cuda.Event()
+            cleared.record(side)
+        hook = _HOOK_FN(lambda _ctx: main.wait_event(cleared))
+
+    a = _ForwardArgs()
+    a.P, a.D, a.W, a.H = P, st.D, W, H
+    p = lambda t: None if t is None else t.data_ptr()
+    if raw is not None:
+        r = {k: _f32(v, k) for k, v in raw.items()}
+        n_rest = 0 if r["features_rest"] is None else r["features_rest"].shape[1]
+        st.M = 1 + n_rest
+        a.raw, a.M = 1, st.M
+        a.scales, a.rotations, a.opacities = p(r["scaling"]), p(r["rotation"]), p(r["opacity"])
+        a.shs, a.shs_rest = p(r["features_dc"]), p(r["features_rest"])
+        held = r
+    else:
+        a.raw, a.M = 0, st.M
+        a.scales, a.rotations, a.opacities = p(scales), p(rotations), p(opacities)
+        a.shs, a.colors_precomp, a.cov3D_precomp = p(shs), p(colors_precomp), p(cov3D_precomp)
+        held = None
+    a.means3D = p(means3D)
+    a.viewmatrix, a.projmatrix, a.campos, a.bg = p(st.view), p(st.proj), p(st.campos), p(st.bg)
+    a.scale_modifier, a.tanfovx, a.tanfovy = float(s.scale_modifier), float(s.tanfovx), float(s.tanfovy)
+    a.prefiltered, a.reference_lists, a.debug, a.keep_tile_ids = int(bool(s.prefiltered)), ref_lists, int(bool(s.debug)), int(keep_tile_ids)
+    a.out_color, a.radii, a.visible = p(st.color), p(st.radii), p(st.visible)
+    a.workspace, a.workspace_bytes = ws.data_ptr(), nbytes
+    status = _status_word(dev)
+    a.h_totals, a.event, a.status = _pinned_totals(dev).data_ptr(), _read_back_event(dev), status.data_ptr()
+    if hook is not None:
+        a.before_blend = C.cast(hook, C.c_void_p)
+    if _timer is not None and "blend_fwd" in _timer.exact:
+        a.blend_start_event, a.blend_stop_event = _timer.kernel_pair("blend_fwd")
+    out = _ForwardOut()
+    cb = _RESIZE_FN(resize)
+    rc = _lib.gsr_forward(C.byref(a), cb, None, C.byref(out), _stream())
+    del held
+    if rc == GSR_E_EARLIER:
+        status.zero_()
+        raise RasterizerFault(int(out.carried_status))
+    if rc != 0:
+        raise RuntimeError(f"libgsr_hip forward failed ({rc}): {_lib.gsr_last_error().decode()}")
+    N = int(out.N)
+    st.num_rendered, st.num_visible = N, int(out.V)
+    base, lists = ws.data_ptr(), keep["lists"]
+
+    width = {torch.int32: 4, torch.float32: 4, torch.int64: 8}
+
+    def view(buf, origin, ptr, count, dtype, shape):
+        off = ptr - origin
+        return buf[off:off + count * width[dtype]].view(dtype).view(shape)
+
+    tiles = ((W + TILE - 1) // TILE) * ((H + TILE - 1) // TILE)
+    st.records = view(ws, base, out.records, P * REC_WORDS, torch.int32, (P, REC_WORDS))
+    st.depth_keys = view(ws, base, out.depth_keys, P, torch.int32, (P,))
+    st.sorted_vals = view(ws, base, out.sorted_vals, P, torch.int64, (P,))
+    st.ranges = view(ws, base, out.ranges, tiles * 2, torch.int32, (tiles, 2))
+    st.final_T = view(ws, base, out.final_T, H * W, torch.float32, (H, W))
+    st.n_contrib = view(ws, base, out.n_contrib, H * W, torch.int32, (H, W))
+    st.point_list = view(lists, lists.data_ptr(), out.point_list, N, torch.int32, (N,))
+    st.tile_ids_sorted = (view(lists, lists.data_ptr(), out.tile_ids_sorted, N, torch.int32, (N,))
+                          if keep_tile_ids else None)
+
+
 def rasterize_forward(s: GaussianRasterizationSettings, means3D, opacities, shs=None, colors_precomp=None,
                       scales=None, rotations=None, cov3D_precomp=None, keep_tile_ids: bool = False,
                       raw: Optional[dict] = None, prepare_backward: bool = False,
-                      reference_lists: Optional[bool] = None) -> ForwardState:
+                      reference_lists: Optional[bool] = None, single_call: Optional[bool] = None) -> ForwardState:
     """preprocess -> bin -> blend on the current stream; one host read-back
     (the instance count) in the middle, as in the module it replaces.
     With ``raw`` (features_dc, features_rest, scaling, rotation, opacity: the model's raw
     parameters) the activations run inside the preprocess kernel and the activated
     arguments are ignored.  ``prepare_backward`` also clears the accumulator of the blend backward
     during the forward (off the critical path).  ``reference_lists`` (default: the module-level
-    REFERENCE_LISTS) asks for the replaced module's own tile lists instead of the shorter ones."""
+    REFERENCE_LISTS) asks for the replaced module's own tile lists instead of the shorter ones.
+    ``single_call`` (default: the module-level SINGLE_CALL) runs the forward as one gsr_forward call
+    instead of the sequence of stage calls; the results are the same bit for bit."""
     means3D = _f32(means3D, "means3D")
     dev = means3D.device if means3D is not None else s.bg.device
     st = ForwardState()
@@ -341,6 +480,14 @@ def rasterize_forward(s: GaussianRasterizationSettings, means3D, opacities, shs=
     st.M = 0 if shs is None else shs.shape[1]
     st.view, st.proj = _f32(s.viewmatrix, "viewmatrix"), _f32(s.projmatrix, "projmatrix")
     st.campos, st.bg = _f32(s.campos, "campos"), _f32(s.bg, "bg")
+    st.dsplat = None
+    ref_lists = int(REFERENCE_LISTS if reference_lists is None else reference_lists)
+    # a timer that brackets stages with events needs the stage calls; one that only wants the blend kernels' own
+    # events does not
+    if (SINGLE_CALL if single_call is None else single_call) and (_timer is None or _timer.only == frozenset()):
+        _forward_single_call(s, st, dev, means3D, opacities, shs, colors_precomp, scales, rotations, cov3D_precomp,
+                             keep_tile_ids, raw, prepare_backward, ref_lists)
+        return st
     stream = _stream()
     u32 = dict(dtype=torch.int32, device=dev)   # uint32 payloads carried in int32 tensors
     st.records = torch.empty((P, REC_WORDS), **u32)
@@ -355,10 +502,8 @@ def rasterize_forward(s: GaussianRasterizationSettings, means3D, opacities, shs=
     st.n_contrib = torch.empty((H, W), **u32)
     st.tile_ids_sorted = None
 
-    st.dsplat = None
     N = E1 = E2 = V = 0
     if P > 0:
-        ref_lists = int(REFERENCE_LISTS if reference_lists is None else reference_lists)
         totals = torch.empty((_lib.gsr_totals_words(P),), **u32)
         sort_vals = torch.empty((P,), dtype=torch.int64, device=dev)
         status = _status_word(dev)

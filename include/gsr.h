@@ -54,6 +54,7 @@ extern "C" {
 #define GSR_E_SCRATCH (-3)   /* scratch buffer too small or misaligned                       */
 #define GSR_E_SORT (-4)      /* the depth sort gave up waiting (see gsr_bin_sort_status)     */
 #define GSR_E_TOO_LARGE (-5) /* the input exceeds a fixed capacity (gsr_bin_sort_static)      */
+#define GSR_E_EARLIER (-6)   /* gsr_forward: the status word carries an earlier call's failure */
 
 /* Bits of the caller's device-side status word (see gsr_bin_lists). */
 #define GSR_STATUS_SORT 1u   /* a list builder found that its depth sort had given up        */
@@ -232,6 +233,59 @@ int gsr_bin_lists(int P, uint32_t V, uint32_t N, uint32_t E1, uint32_t E2, int W
 int gsr_blend_fwd(int W, int H, const uint32_t* ranges, const uint32_t* point_list,
                   const uint32_t* records, const float* bg, float* out_color, float* final_T,
                   uint32_t* n_contrib, void* stream);
+
+/* ---- The forward in one call -------------------------------------------------
+ * Stages 1-3 behind one entry point, the shape of the replaced module's own
+ * native forward (one call per GaussianRasterizer.forward,
+ * gaussian_renderer/__init__.py:85-93; memory whose size is only known half way
+ * obtained through a callback into the host's allocator).  Results are those of
+ * the stage entry points, bit for bit; what it saves is host time: one transition
+ * into native code and two or three buffers per render instead of a dozen.
+ *
+ * The caller passes the inputs of stage 1, the user-visible outputs (out_color,
+ * radii, optionally visible), one WORKSPACE of gsr_forward_workspace_bytes(P, W, H)
+ * bytes (256-byte aligned) for everything else whose size is known up front, a
+ * page-locked host buffer of 8 words and an event (gsr_event_create) for the
+ * read-back, and optionally a status word (see gsr_bin_lists).  Once the list
+ * sizes have arrived, `resize(resize_ctx, bytes)` is called ONCE for the memory
+ * of the tile lists and the list builder's scratch (256-byte aligned device
+ * memory, or NULL to fail); it must stay valid as long as the lists are used.
+ * The call waits for the read-back (nothing else), and in `debug` mode after
+ * every stage.  GsrForwardOut receives the list sizes and the device addresses
+ * of what a backward pass (and a test) needs: records, ranges, final_T,
+ * n_contrib, depth_keys, sorted_vals inside the workspace, point_list (and
+ * tile_ids_sorted when keep_tile_ids is set) inside the resize memory.
+ * raw != 0: the inputs are the model's raw parameters as for
+ * gsr_preprocess_fwd_raw (shs = features_dc, shs_rest = features_rest, M = 1 +
+ * n_rest, opacities / scales / rotations un-activated).
+ * before_blend (optional): called on the host after the list builder has been
+ * enqueued and before the blend is, e.g. to make `stream` wait for work the
+ * caller put on another stream meanwhile.
+ * If totals[4] shows that an earlier call on the same status word built no
+ * lists, the call stops before its own lists with GSR_E_EARLIER
+ * (out->carried_status holds the bits; clearing the word is the caller's). */
+typedef void* (*gsr_resize_fn)(void* ctx, size_t bytes);
+typedef struct GsrForwardArgs {
+  int P, D, M, raw;
+  const float* means3D; const float* scales; const float* rotations; const float* opacities;
+  const float* shs; const float* shs_rest; const float* colors_precomp; const float* cov3D_precomp;
+  const float* viewmatrix; const float* projmatrix; const float* campos; const float* bg;
+  float scale_modifier, tanfovx, tanfovy;
+  int W, H, prefiltered, reference_lists, debug, keep_tile_ids;
+  float* out_color; int32_t* radii; uint8_t* visible;
+  void* workspace; size_t workspace_bytes;
+  uint32_t* h_totals; void* event; uint32_t* status;
+  void (*before_blend)(void* ctx); void* before_blend_ctx;
+  void* blend_start_event; void* blend_stop_event;   /* optional, as for gsr_blend_fwd_timed */
+} GsrForwardArgs;
+typedef struct GsrForwardOut {
+  uint32_t N, V, E1, E2, carried_status;
+  uint32_t* records; uint32_t* depth_keys; uint64_t* sorted_vals; uint32_t* ranges; float* final_T;
+  uint32_t* n_contrib; uint32_t* point_list; uint32_t* tile_ids_sorted;
+} GsrForwardOut;
+size_t gsr_forward_workspace_bytes(int P, int W, int H);
+int gsr_forward(const GsrForwardArgs* args, gsr_resize_fn resize, void* resize_ctx, GsrForwardOut* out,
+                void* stream);
 
 /* ---- Stage 4: blend backward ---------------------------------------------
  * dL_dpix (3,H,W) -> per-Gaussian sums, accumulated into dL_dsplat (P,16) fp32

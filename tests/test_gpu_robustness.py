@@ -188,3 +188,51 @@ def test_a_sort_that_gives_up_in_release_mode_surfaces_at_the_next_forward():
         again = _forward(dgr, s, c)
     torch.cuda.synchronize()
     assert torch.equal(again.color, good.color) and torch.equal(again.point_list, good.point_list)
+
+
+@pytest.mark.parametrize("raw", [False, True])
+def test_single_call_forward_equals_the_stage_calls(raw):
+    """gsr_forward (one call, one workspace, lists through the resize callback) against the sequence of
+    stage entry points: every output and every intermediate buffer bit for bit, and the same gradients."""
+    import diff_gaussian_rasterization as dgr
+    from gsplat_host.model import GaussianParams
+    cloud, cam, bg, _ = make_scene(40_000, 500, 300, sh_degree=3, seed=12, bg=(0.1, 0.2, 0.3))
+    s = _gpu_settings(cam, bg, 3, 1.0)
+    c = cloud.to("cuda")
+    kw = dict(keep_tile_ids=True, prepare_backward=True)
+    if raw:
+        m = GaussianParams(cloud, device="cuda")
+        rawd = dict(features_dc=m._features_dc.detach(), features_rest=m._features_rest.detach(),
+                    scaling=m._scaling.detach(), rotation=m._rotation.detach(), opacity=m._opacity.detach())
+        one = dgr.rasterize_forward(s, c.xyz, None, raw=rawd, single_call=True, **kw)
+        many = dgr.rasterize_forward(s, c.xyz, None, raw=rawd, single_call=False, **kw)
+    else:
+        one = _forward(dgr, s, c, single_call=True, **kw)
+        many = _forward(dgr, s, c, single_call=False, **kw)
+    torch.cuda.synchronize()
+    assert one.num_rendered == many.num_rendered > 0 and one.num_visible == many.num_visible
+    vis = many.radii > 0
+    for name in ("color", "radii", "visible", "final_T", "n_contrib", "ranges", "point_list", "tile_ids_sorted",
+                 "depth_keys"):
+        assert torch.equal(getattr(one, name), getattr(many, name)), name
+    assert torch.equal(one.records[vis], many.records[vis])
+    V = many.num_visible
+    assert torch.equal(one.sorted_vals[:V], many.sorted_vals[:V])
+    d = torch.randn(one.color.shape, device="cuda", generator=torch.Generator(device="cuda").manual_seed(4))
+    if raw:
+        g1 = dgr.rasterize_backward_raw(s, one, d, c.xyz, rawd)
+        g2 = dgr.rasterize_backward_raw(s, many, d, c.xyz, rawd)
+    else:
+        g1 = dgr.rasterize_backward(s, one, d, c.xyz, shs=c.features, scales=c.scaling, rotations=c.rotation)
+        g2 = dgr.rasterize_backward(s, many, d, c.xyz, shs=c.features, scales=c.scaling, rotations=c.rotation)
+    for k in g1:
+        if g1[k] is not None:
+            assert float((g1[k] - g2[k]).abs().max()) <= 2e-5 * float(g2[k].abs().max() + 1e-20), k
+
+    # empty input and a fully culled cloud through the single call
+    behind = c.xyz.clone()
+    behind[:, 2] += 100.0
+    st = dgr.rasterize_forward(s, behind, c.opacity, shs=c.features, scales=c.scaling, rotations=c.rotation,
+                               single_call=True)
+    torch.cuda.synchronize()
+    assert st.num_rendered == 0 and torch.equal(st.color, bg.cuda()[:, None, None].expand_as(st.color))
