@@ -150,10 +150,12 @@ class Scene:
         self.params = [p for p in self.model.parameters()]
 
 
-def measure(scene, dgr, fused, steps, warmup, use_dist=False, dp_grads=False, opt=None, stage_table=True):
-    """`steps` timed train steps of one scene: wall time over all of them (between barriers), the forward
-    render by device events inside them, the two blend kernels by the launch's own events; then, untimed,
-    one more pass with every stage bracketed for the per-stage table."""
+def measure(scene, dgr, fused, steps, warmup, use_dist=False, dp_grads=False, opt=None, stage_table=True,
+            events_in_timed_steps=False):
+    """`steps` timed train steps of one scene: wall time over all of them (between barriers) and the forward
+    render by device events inside them; then, untimed, the same steps again with the two blend kernels
+    stamped by their launches' own events (inside the timed steps instead with `events_in_timed_steps`:
+    such launches cost the step ~0.04 ms each), and once more with every stage bracketed for the per-stage table."""
     from gsplat_host.loss import photometric_loss
     from gsplat_host.optim import all_reduce_gradients
     from gsplat_host.render import PipelineParams, render
@@ -199,12 +201,18 @@ def measure(scene, dgr, fused, steps, warmup, use_dist=False, dp_grads=False, op
     for _ in range(warmup):
         step(False)
     barrier()
-    dgr.set_stage_timer(timer)
+    if events_in_timed_steps:
+        dgr.set_stage_timer(timer)
     t0 = time.perf_counter()
     for _ in range(steps):
         step(True)
     barrier()
     elapsed = time.perf_counter() - t0
+    if not events_in_timed_steps:
+        dgr.set_stage_timer(timer)
+        for _ in range(steps):
+            step(False)
+        barrier()
     dgr.set_stage_timer(None)
     exact = timer.exact_ms()
     timer.close()
@@ -229,6 +237,9 @@ def main():
     ap.add_argument("--warmup", type=int, default=5)
     ap.add_argument("--workload", default="c3", choices=sorted(WORKLOADS))
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--events-in-timed-steps", action="store_true",
+                    help="stamp the blend kernels with their launches' own events inside the timed steps instead of in "
+                         "a pass of the same steps right after them (such launches slow the step down a little)")
     ap.add_argument("--no-variants", action="store_true",
                     help="skip the extra measurements of the default line (reference operator API, opacity-0.1 scene)")
     ap.add_argument("--unfused", action="store_true",
@@ -263,7 +274,8 @@ def main():
     scene = Scene(args.workload, dev, rank)
     P, W, H, deg = scene.P, scene.W, scene.H, scene.deg
     opt = GaussianAdam.for_model(scene.model)
-    m = measure(scene, dgr, not args.unfused, args.steps, args.warmup, use_dist, args.dp_grads, opt)
+    m = measure(scene, dgr, not args.unfused, args.steps, args.warmup, use_dist, args.dp_grads, opt,
+                events_in_timed_steps=args.events_in_timed_steps)
 
     elapsed, render_ms = m["elapsed"], m["render_ms"]
     if use_dist:
@@ -328,8 +340,10 @@ def main():
                          "traffic": lim.get("measured_hbm_bytes"),
                          "traffic_unit": "bytes/launch (rocprofv3 FETCH_SIZE x2 + WRITE_SIZE)",
                          "kernel_ms": round(dom_ms, 4),
-                         "kernel_ms_from": "HIP events stamped by the kernel's launch (its own start and end), mean "
-                                           f"over the {args.steps} timed steps",
+                         "kernel_ms_from": "HIP events stamped by the kernel's launch (its own start and end), mean over "
+                                           + (f"the {args.steps} timed steps" if args.events_in_timed_steps else
+                                              f"{args.steps} steps run right after the timed ones (inside them such "
+                                              "launches would slow the step down)"),
                          **lim},
             "kernels": kernels,
             "optimizer": {"what": "fused Adam over the six parameter tensors, outside the timed step as in the reference",

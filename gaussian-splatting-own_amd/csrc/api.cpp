@@ -31,6 +31,15 @@ extern "C" void* gsr_event_create(void) {
   return e;
 }
 
+extern "C" void* gsr_event_create_untimed(void) {
+  hipEvent_t e = nullptr;
+  if (hipEventCreateWithFlags(&e, hipEventDisableTiming) != hipSuccess) {
+    gsr::fail(GSR_E_LAUNCH, "event_create_untimed: %s", hipGetErrorString(hipGetLastError()));
+    return nullptr;
+  }
+  return e;
+}
+
 extern "C" void gsr_event_destroy(void* event) {
   if (event) (void)hipEventDestroy((hipEvent_t)event);
 }

@@ -88,6 +88,7 @@ extern "C" int gsr_forward(const GsrForwardArgs* a, gsr_resize_fn resize, void* 
                               w.depth_keys, nullptr, w.sort_vals, w.totals, a->status, a->visible, stream);
     if (rc) return rc;
     if ((rc = checkpoint("preprocess"))) return rc;
+    if (a->after_preprocess) a->after_preprocess(a->hook_ctx);
     // the list sizes (and the carried status word) travel to the host while the GPU sorts by depth
     hipError_t e = hipMemcpyAsync(a->h_totals, w.totals, 8 * sizeof(uint32_t), hipMemcpyDeviceToHost, st);
     if (e == hipSuccess) e = hipEventRecord((hipEvent_t)a->event, st);
@@ -125,7 +126,7 @@ extern "C" int gsr_forward(const GsrForwardArgs* a, gsr_resize_fn resize, void* 
                          P > 0 ? w.totals : nullptr, a->status, lists_scratch, lists_bytes, stream);
   if (rc) return rc;
   if ((rc = checkpoint("bin_lists"))) return rc;
-  if (a->before_blend) a->before_blend(a->before_blend_ctx);
+  if (a->before_blend) a->before_blend(a->hook_ctx);
   rc = gsr_blend_fwd_timed(W, H, w.ranges, out->point_list, w.records, a->bg, a->out_color, w.final_T, w.n_contrib,
                            a->blend_start_event, a->blend_stop_event, stream);
   if (rc) return rc;

@@ -59,7 +59,7 @@ class _ForwardArgs(C.Structure):
                 ("out_color", C.c_void_p), ("radii", C.c_void_p), ("visible", C.c_void_p),
                 ("workspace", C.c_void_p), ("workspace_bytes", C.c_size_t),
                 ("h_totals", C.c_void_p), ("event", C.c_void_p), ("status", C.c_void_p),
-                ("before_blend", C.c_void_p), ("before_blend_ctx", C.c_void_p),
+                ("after_preprocess", C.c_void_p), ("before_blend", C.c_void_p), ("hook_ctx", C.c_void_p),
                 ("blend_start_event", C.c_void_p), ("blend_stop_event", C.c_void_p)]
 
 
@@ -107,6 +107,7 @@ def _load():
     lib.gsr_blend_fwd_timed.argtypes = [ci, ci, vp, vp, vp, vp, vp, vp, vp, vp, vp, vp]
     lib.gsr_blend_bwd_timed.argtypes = [ci, ci, vp, vp, vp, vp, vp, vp, vp, vp, vp, vp, vp]
     lib.gsr_event_create.restype = vp
+    lib.gsr_event_create_untimed.restype = vp
     lib.gsr_event_destroy.argtypes, lib.gsr_event_destroy.restype = [vp], None
     lib.gsr_event_elapsed_ms.argtypes = [vp, vp, C.POINTER(C.c_float)]
     lib.gsr_preprocess_bwd.argtypes = [ci, ci, ci, vp, vp, cf, vp, vp, vp, vp, vp, vp, ci, ci, cf, cf, vp, vp,
@@ -360,7 +361,7 @@ def _read_back_event(dev: torch.device):
     """The event a single-call forward marks its read-back with, one per (host thread, device)."""
     d = _per_device(dev)
     if "event" not in d:
-        d["event"] = _lib.gsr_event_create()
+        d["event"] = _lib.gsr_event_create_untimed()
         if not d["event"]:
             raise RuntimeError("libgsr_hip: " + _lib.gsr_last_error().decode())
     return d["event"]
@@ -383,19 +384,24 @@ def _forward_single_call(s, st, dev, means3D, opacities, shs, colors_precomp, sc
         keep["lists"] = torch.empty((bytes_,), **u8)
         return keep["lists"].data_ptr()
 
-    hook = None
+    hooks = None
     if prepare_backward and _OVERLAP and P > 0:
-        # the accumulator of the blend backward is cleared on a second stream while this one runs the forward
+        # The accumulator of the blend backward is cleared on a second stream beside the depth sort and the
+        # list builder (short dependent launches that leave HBM idle): the library calls back once the
+        # preprocess is enqueued, and again before it enqueues the blend, which then waits for the fill.
         main, side = torch.cuda.current_stream(dev), _side_stream(dev)
         st.dsplat = torch.empty((P, GRAD_WORDS), dtype=torch.float32, device=dev)
-        handed_out = torch.cuda.Event()
-        handed_out.record(main)
-        side.wait_event(handed_out)
-        with torch.cuda.stream(side):
-            st.dsplat.zero_()
-            cleared = torch.cuda.Event()
-            cleared.record(side)
-        hook = _HOOK_FN(lambda _ctx: main.wait_event(cleared))
+        cleared = torch.cuda.Event()
+
+        def start_fill(_ctx):
+            handed_out = torch.cuda.Event()
+            handed_out.record(main)
+            side.wait_event(handed_out)
+            with torch.cuda.stream(side):
+                st.dsplat.zero_()
+                cleared.record(side)
+
+        hooks = (_HOOK_FN(start_fill), _HOOK_FN(lambda _ctx: main.wait_event(cleared)))
 
     a = _ForwardArgs()
     a.P, a.D, a.W, a.H = P, st.D, W, H
@@ -421,8 +427,8 @@ def _forward_single_call(s, st, dev, means3D, opacities, shs, colors_precomp, sc
     a.workspace, a.workspace_bytes = ws.data_ptr(), nbytes
     status = _status_word(dev)
     a.h_totals, a.event, a.status = _pinned_totals(dev).data_ptr(), _read_back_event(dev), status.data_ptr()
-    if hook is not None:
-        a.before_blend = C.cast(hook, C.c_void_p)
+    if hooks is not None:
+        a.after_preprocess, a.before_blend = C.cast(hooks[0], C.c_void_p), C.cast(hooks[1], C.c_void_p)
     if _timer is not None and "blend_fwd" in _timer.exact:
         a.blend_start_event, a.blend_stop_event = _timer.kernel_pair("blend_fwd")
     out = _ForwardOut()

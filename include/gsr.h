@@ -258,9 +258,10 @@ int gsr_blend_fwd(int W, int H, const uint32_t* ranges, const uint32_t* point_li
  * raw != 0: the inputs are the model's raw parameters as for
  * gsr_preprocess_fwd_raw (shs = features_dc, shs_rest = features_rest, M = 1 +
  * n_rest, opacities / scales / rotations un-activated).
- * before_blend (optional): called on the host after the list builder has been
- * enqueued and before the blend is, e.g. to make `stream` wait for work the
- * caller put on another stream meanwhile.
+ * after_preprocess, before_blend (optional, both get hook_ctx): called on the host
+ * right after stage 1 has been enqueued, and after the list builder has been
+ * enqueued and before the blend is: e.g. to start work on another stream beside the
+ * depth sort and to make `stream` wait for it before the blend.
  * If totals[4] shows that an earlier call on the same status word built no
  * lists, the call stops before its own lists with GSR_E_EARLIER
  * (out->carried_status holds the bits; clearing the word is the caller's). */
@@ -275,7 +276,7 @@ typedef struct GsrForwardArgs {
   float* out_color; int32_t* radii; uint8_t* visible;
   void* workspace; size_t workspace_bytes;
   uint32_t* h_totals; void* event; uint32_t* status;
-  void (*before_blend)(void* ctx); void* before_blend_ctx;
+  void (*after_preprocess)(void* ctx); void (*before_blend)(void* ctx); void* hook_ctx;
   void* blend_start_event; void* blend_stop_event;   /* optional, as for gsr_blend_fwd_timed */
 } GsrForwardArgs;
 typedef struct GsrForwardOut {
@@ -312,6 +313,7 @@ int gsr_blend_bwd(int W, int H, const uint32_t* ranges, const uint32_t* point_li
  * between the two to *h_ms (host memory).  Measurement only: the reference has
  * no counterpart (its two torch events span a whole iteration, train.py:44-45,67,95). */
 void* gsr_event_create(void);
+void* gsr_event_create_untimed(void);   /* for ordering and waiting only (cheaper to record) */
 void gsr_event_destroy(void* event);
 int gsr_event_elapsed_ms(void* start_event, void* stop_event, float* h_ms);
 int gsr_blend_fwd_timed(int W, int H, const uint32_t* ranges, const uint32_t* point_list,
