@@ -7,9 +7,11 @@ concatenation for SH features, ``:33-41``), plus ``get_covariance``
 (``:27-31,117-118``); and the pieces either side of it: initialisation from a
 point cloud with the 3-nearest-neighbour scales (``:124-147``), the
 densification statistics fed by the rasterizer's screen-space gradient
-(``:405-407``, ``train.py:113-116``) and the PLY model file (``:191-256``).
-Densification itself (clone / split / prune, optimiser surgery) is host
-bookkeeping outside the rasterizer path and is not reproduced.
+(``:405-407``, ``train.py:113-116``), the PLY model file (``:191-256``), and the
+host bookkeeping that changes the number of Gaussians between steps
+(``:120-122, 179-189, 291-403``: SH degree ramp, opacity reset, clone / split /
+prune) with the checkpoint tuple (``:61-93``), all on top of ``GaussianAdam``'s
+state surgery.  These are plain PyTorch tensor operations, as in the reference.
 """
 from __future__ import annotations
 
@@ -89,6 +91,109 @@ class GaussianParams(nn.Module):
         opac = inverse_sigmoid(0.1 * torch.ones((n, 1), dtype=torch.float, device=device))
         m._set_raw(pts, feats[:, 0:1, :], feats[:, 1:, :], opac, scales, rots, device)
         return m
+
+    # ---- bookkeeping between steps ---------------------------------------------------------------------------
+    GROUPS = (("xyz", "_xyz"), ("f_dc", "_features_dc"), ("f_rest", "_features_rest"), ("opacity", "_opacity"),
+              ("scaling", "_scaling"), ("rotation", "_rotation"))
+
+    def training_setup(self, optimizer, percent_dense: float = 0.01) -> None:
+        """The part of training_setup (scene/gaussian_model.py:149-152) that belongs to the model: the
+        optimiser whose state follows the model through densification, ``percent_dense``, fresh statistics."""
+        self.optimizer, self.percent_dense = optimizer, percent_dense
+        n, dev = self._xyz.shape[0], self._xyz.device
+        self.xyz_gradient_accum = torch.zeros((n, 1), device=dev)
+        self.denom = torch.zeros((n, 1), device=dev)
+
+    def _adopt(self, tensors) -> None:
+        for group, attr in self.GROUPS:
+            setattr(self, attr, tensors[group])
+
+    def oneupSHdegree(self) -> None:
+        """:120-122."""
+        if self.active_sh_degree < self.max_sh_degree:
+            self.active_sh_degree += 1
+
+    def reset_opacity(self) -> None:
+        """:179-182: no opacity above 0.01; the opacity group's moments start again."""
+        new = inverse_sigmoid(torch.min(self.get_opacity.detach(), torch.ones_like(self._opacity) * 0.01))
+        self._opacity = self.optimizer.replace_tensor("opacity", new)
+
+    def prune_points(self, mask: torch.Tensor) -> None:
+        """:291-305: removes the Gaussians selected by ``mask``."""
+        keep = ~mask
+        self._adopt(self.optimizer.prune(keep))
+        self.xyz_gradient_accum = self.xyz_gradient_accum[keep]
+        self.denom = self.denom[keep]
+        self.max_radii2D = self.max_radii2D[keep]
+
+    def densification_postfix(self, new_xyz, new_features_dc, new_features_rest, new_opacities, new_scaling,
+                              new_rotation) -> None:
+        """:329-347: appends Gaussians; the densification statistics of ALL Gaussians start again."""
+        self._adopt(self.optimizer.cat_tensors({"xyz": new_xyz, "f_dc": new_features_dc, "f_rest": new_features_rest,
+                                                "opacity": new_opacities, "scaling": new_scaling,
+                                                "rotation": new_rotation}))
+        n, dev = self._xyz.shape[0], self._xyz.device
+        self.xyz_gradient_accum = torch.zeros((n, 1), device=dev)
+        self.denom = torch.zeros((n, 1), device=dev)
+        self.max_radii2D = torch.zeros((n,), device=dev)
+
+    @torch.no_grad()
+    def densify_and_split(self, grads, grad_threshold, scene_extent, N: int = 2, generator=None) -> None:
+        """:349-372: large Gaussians with a large screen-space gradient become N smaller ones, sampled
+        from the Gaussian itself (scales divided by 0.8 N); the original goes."""
+        n_init, dev = self._xyz.shape[0], self._xyz.device
+        padded = torch.zeros((n_init,), device=dev)
+        padded[:grads.shape[0]] = grads.squeeze()
+        sel = (padded >= grad_threshold) & (self.get_scaling.max(dim=1).values > self.percent_dense * scene_extent)
+        stds = self.get_scaling[sel].repeat(N, 1)
+        samples = torch.normal(mean=torch.zeros_like(stds), std=stds, generator=generator)
+        rots = quaternion_to_matrix(self._rotation[sel]).repeat(N, 1, 1)
+        new_xyz = torch.bmm(rots, samples.unsqueeze(-1)).squeeze(-1) + self._xyz[sel].repeat(N, 1)
+        new_scaling = torch.log(self.get_scaling[sel].repeat(N, 1) / (0.8 * N))
+        self.densification_postfix(new_xyz, self._features_dc[sel].repeat(N, 1, 1),
+                                   self._features_rest[sel].repeat(N, 1, 1), self._opacity[sel].repeat(N, 1),
+                                   new_scaling, self._rotation[sel].repeat(N, 1))
+        self.prune_points(torch.cat((sel, torch.zeros((N * int(sel.sum()),), device=dev, dtype=torch.bool))))
+
+    @torch.no_grad()
+    def densify_and_clone(self, grads, grad_threshold, scene_extent) -> None:
+        """:374-387: small Gaussians with a large screen-space gradient are duplicated in place."""
+        sel = (torch.norm(grads, dim=-1) >= grad_threshold) & \
+              (self.get_scaling.max(dim=1).values <= self.percent_dense * scene_extent)
+        self.densification_postfix(self._xyz[sel], self._features_dc[sel], self._features_rest[sel], self._opacity[sel],
+                                   self._scaling[sel], self._rotation[sel])
+
+    @torch.no_grad()
+    def densify_and_prune(self, max_grad, min_opacity, extent, max_screen_size, generator=None) -> None:
+        """:389-403 (train.py:118-120 calls it every 100 iterations)."""
+        grads = self.xyz_gradient_accum / self.denom
+        grads[grads.isnan()] = 0.0
+        self.densify_and_clone(grads, max_grad, extent)
+        self.densify_and_split(grads, max_grad, extent, generator=generator)
+        prune_mask = (self.get_opacity < min_opacity).squeeze()
+        if max_screen_size:
+            big_points_vs = self.max_radii2D > max_screen_size
+            big_points_ws = self.get_scaling.max(dim=1).values > 0.1 * extent
+            prune_mask = prune_mask | big_points_vs | big_points_ws
+        self.prune_points(prune_mask)
+
+    def capture(self):
+        """The checkpoint tuple of :61-75, the optimiser's state in torch.optim.Adam's layout."""
+        return (self.active_sh_degree, self._xyz, self._features_dc, self._features_rest, self._scaling, self._rotation,
+                self._opacity, self.max_radii2D, self.xyz_gradient_accum, self.denom, self.optimizer.state_dict(),
+                getattr(self, "spatial_lr_scale", 1.0))
+
+    def restore(self, model_args, optimizer_factory, percent_dense: float = 0.01) -> None:
+        """:77-93.  ``optimizer_factory(model)`` builds the optimiser for the restored tensors (the reference
+        calls training_setup with its training arguments), then the saved state goes in."""
+        (self.active_sh_degree, xyz, f_dc, f_rest, scaling, rotation, opacity, max_radii2D, grad_accum, denom, opt_dict,
+         self.spatial_lr_scale) = model_args
+        dev = xyz.device
+        self._set_raw(xyz, f_dc, f_rest, opacity, scaling, rotation, dev)
+        self.max_radii2D = max_radii2D
+        self.training_setup(optimizer_factory(self), percent_dense)
+        self.xyz_gradient_accum, self.denom = grad_accum, denom
+        self.optimizer.load_state_dict(opt_dict)
 
     def add_densification_stats(self, viewspace_point_tensor, update_filter, radii=None):
         """scene/gaussian_model.py:405-407 (and train.py:115 when ``radii`` is given): the norm of the

@@ -143,8 +143,8 @@ class GaussianAdam:
         if len(params) > MAX_TENSORS:
             raise ValueError(f"at most {MAX_TENSORS} tensors per fused step")
         for name, p in params.items():
-            if not p.is_cuda or p.dtype != torch.float32 or not p.is_contiguous():
-                raise ValueError(f"{name}: parameters must be contiguous float32 tensors on the GPU")
+            if p.dtype != torch.float32 or not p.is_contiguous():
+                raise ValueError(f"{name}: parameters must be contiguous float32 tensors")
         self.params, self.lrs = dict(params), dict(lrs)
         self.betas, self.eps = betas, eps
         self.step_count = 0
@@ -171,9 +171,94 @@ class GaussianAdam:
         self.lrs["xyz"] = lr
         return lr
 
+    # ---- the optimiser surgery of densification (scene/gaussian_model.py:258-327): the number of Gaussians
+    # changes between steps, the moments of the survivors stay ------------------------------------------------
+    @torch.no_grad()
+    def replace_tensor(self, name: str, tensor: torch.Tensor) -> torch.nn.Parameter:
+        """replace_tensor_to_optimizer (:258-271): a new value for one tensor, its moments start again at zero,
+        the step count stays (torch.optim.Adam keeps ``state["step"]`` there too)."""
+        p = torch.nn.Parameter(tensor.detach().contiguous().requires_grad_(True))
+        self.params[name] = p
+        self.exp_avg[name] = torch.zeros_like(p)
+        self.exp_avg_sq[name] = torch.zeros_like(p)
+        return p
+
+    @torch.no_grad()
+    def prune(self, keep: torch.Tensor) -> Dict[str, torch.nn.Parameter]:
+        """_prune_optimizer (:273-289): keeps the rows selected by the boolean mask ``keep`` of every tensor and
+        of both moments; returns the new parameters by group name."""
+        for name, p in self.params.items():
+            self.exp_avg[name] = self.exp_avg[name][keep].contiguous()
+            self.exp_avg_sq[name] = self.exp_avg_sq[name][keep].contiguous()
+            self.params[name] = torch.nn.Parameter(p.detach()[keep].contiguous().requires_grad_(True))
+        return dict(self.params)
+
+    @torch.no_grad()
+    def cat_tensors(self, extension: Dict[str, torch.Tensor]) -> Dict[str, torch.nn.Parameter]:
+        """cat_tensors_to_optimizer (:307-327): appends rows to every tensor; the new rows' moments are zero."""
+        if set(extension) != set(self.params):
+            raise ValueError(f"extension must name every tensor: {sorted(self.params)}")
+        for name, p in self.params.items():
+            ext = extension[name].detach().to(p.dtype)
+            self.exp_avg[name] = torch.cat((self.exp_avg[name], torch.zeros_like(ext)), dim=0)
+            self.exp_avg_sq[name] = torch.cat((self.exp_avg_sq[name], torch.zeros_like(ext)), dim=0)
+            self.params[name] = torch.nn.Parameter(torch.cat((p.detach(), ext), dim=0).contiguous().requires_grad_(True))
+        return dict(self.params)
+
+    # ---- checkpoints: torch.optim.Adam's own layout (what the reference saves, scene/gaussian_model.py:73) ----
+    def state_dict(self) -> dict:
+        """The dictionary ``torch.optim.Adam(...).state_dict()`` returns for the reference's six groups
+        (scene/gaussian_model.py:154-163): per parameter ``step`` / ``exp_avg`` / ``exp_avg_sq``, per group the
+        hyper-parameters, ``name`` and the parameter's index."""
+        names = list(self.params)
+        state = {}
+        if self.step_count > 0:
+            for i, n in enumerate(names):
+                state[i] = {"step": torch.tensor(float(self.step_count)), "exp_avg": self.exp_avg[n],
+                            "exp_avg_sq": self.exp_avg_sq[n]}
+        groups = [{"lr": float(self.lrs[n]), "name": n, "betas": tuple(self.betas), "eps": self.eps, "weight_decay": 0,
+                   "amsgrad": False, "maximize": False, "foreach": None, "capturable": False, "differentiable": False,
+                   "fused": None, "params": [i]} for i, n in enumerate(names)]
+        return {"state": state, "param_groups": groups}
+
+    @torch.no_grad()
+    def load_state_dict(self, sd: dict) -> None:
+        """Takes the moments, the step count and the learning rates from a ``torch.optim.Adam`` state dictionary
+        whose groups carry the reference's names (or come in the same order)."""
+        groups = sd["param_groups"]
+        if len(groups) != len(self.params):
+            raise ValueError(f"{len(groups)} parameter groups for {len(self.params)} tensors")
+        steps = set()
+        for i, (g, own) in enumerate(zip(groups, list(self.params))):
+            name = g.get("name", own)
+            if name not in self.params:
+                raise ValueError(f"unknown parameter group {name!r}")
+            if len(g["params"]) != 1:
+                raise ValueError("one tensor per group, as the reference sets them up")
+            p = self.params[name]
+            self.lrs[name] = float(g["lr"])
+            st = sd["state"].get(g["params"][0])
+            if st is None:
+                self.exp_avg[name], self.exp_avg_sq[name] = torch.zeros_like(p), torch.zeros_like(p)
+                continue
+            for key, store in (("exp_avg", self.exp_avg), ("exp_avg_sq", self.exp_avg_sq)):
+                t = st[key]
+                if tuple(t.shape) != tuple(p.shape):
+                    raise ValueError(f"{name}.{key}: shape {tuple(t.shape)} does not match the parameter's {tuple(p.shape)}")
+                store[name] = t.detach().to(device=p.device, dtype=torch.float32).contiguous().clone()
+            steps.add(int(float(st["step"])))
+        if len(steps) > 1:
+            raise ValueError(f"the groups were stepped {sorted(steps)} times: one fused step cannot continue that")
+        self.step_count = steps.pop() if steps else 0
+        if groups and "betas" in groups[0]:
+            self.betas, self.eps = tuple(groups[0]["betas"]), float(groups[0]["eps"])
+
     @torch.no_grad()
     def step(self, grads: Optional[Dict[str, torch.Tensor]] = None, grad_scale: float = 1.0) -> None:
         """One Adam update of every tensor that has a gradient (``grads[name]`` or ``param.grad``)."""
+        for name, p in self.params.items():
+            if not p.is_cuda:
+                raise ValueError(f"{name}: the fused update runs on the GPU only, the parameter is on {p.device}")
         self.step_count += 1
         arr = (_AdamTensor * MAX_TENSORS)()
         n = 0

@@ -56,3 +56,56 @@ def test_loss_goes_down(fused, short_lists):
     first, last = _fit(fused, short_lists)
     print(f"fused={fused} short_lists={short_lists}: mean loss over the six views {first:.5f} -> {last:.5f}", flush=True)
     assert last < 0.7 * first
+
+
+def test_training_through_densification_and_opacity_reset():
+    """The reference's schedule in miniature (train.py:109-128): statistics from the screen-space gradients,
+    densify_and_prune, reset_opacity, with the fused Adam's state following the changing number of Gaussians."""
+    from gsplat_host.cameras import orbit_camera
+    from gsplat_host.loss import photometric_loss
+    from gsplat_host.model import GaussianParams
+    from gsplat_host.optim import GaussianAdam
+    from gsplat_host.render import PipelineParams, render
+    from gsplat_host.synthetic import make_cloud
+    dev = torch.device("cuda", 0)
+    truth = GaussianParams(make_cloud(6_000, sh_degree=1, seed=33, scale_mult=1.2), max_sh_degree=1, device=dev)
+    cams = [orbit_camera(192, 128, angle_deg=45.0 * k, device=dev) for k in range(8)]
+    bg = torch.zeros(3, device=dev)
+    pipe = PipelineParams(fused_activations=True)
+    with torch.no_grad():
+        targets = [render(c, truth, pipe, bg)["render"].clone() for c in cams]
+    # a coarser model of the same scene: a third of the Gaussians, larger
+    model = GaussianParams(make_cloud(2_000, sh_degree=1, seed=34, scale_mult=2.0), max_sh_degree=1, device=dev)
+    model.active_sh_degree = 0
+    opt = GaussianAdam.for_model(model)
+    model.training_setup(opt, percent_dense=0.01)
+    counts, losses = [model._xyz.shape[0]], []
+    gen = torch.Generator(device=dev).manual_seed(1)
+    for it in range(1, 181):
+        opt.update_learning_rate(it)
+        if it % 60 == 0:
+            model.oneupSHdegree()
+        k = it % len(cams)
+        out = render(cams[k], model, pipe, bg)
+        loss = photometric_loss(out["render"], targets[k])
+        loss.backward()
+        losses.append(float(loss.detach()))
+        with torch.no_grad():
+            vis, radii = out["visibility_filter"], out["radii"]
+            model.max_radii2D[vis] = torch.max(model.max_radii2D[vis], radii[vis])          # train.py:115
+            model.add_densification_stats(out["viewspace_points"], vis)                       # train.py:116
+            if it in (60, 120):
+                model.densify_and_prune(0.00005, 0.005, 2.6, 40, generator=gen)               # train.py:118-120
+                counts.append(model._xyz.shape[0])
+            if it == 140:
+                model.reset_opacity()                                                         # train.py:122-123
+        opt.step()
+        opt.zero_grad()
+        n = model._xyz.shape[0]
+        for name, p in opt.params.items():
+            assert p.shape[0] == n and opt.exp_avg[name].shape == p.shape and bool(torch.isfinite(p).all()), name
+    print("Gaussians", counts, "loss %.5f -> %.5f" % (sum(losses[:8]) / 8, sum(losses[-8:]) / 8), flush=True)
+    assert counts[1] != counts[0] and model.active_sh_degree == 1
+    assert opt.step_count == 180 and model.denom.shape[0] == model._xyz.shape[0]
+    assert sum(losses[120:128]) / 8 < 0.8 * sum(losses[:8]) / 8          # it has learnt something by the second densification
+    assert all(l == l and l < 1.0 for l in losses)
