@@ -188,6 +188,16 @@ __device__ __forceinline__ void tile_store_rows(float* __restrict__ dst, int P, 
   for (int e = threadIdx.x; e < rows * R; e += kBlock) dst[base + e] = tile[e];
 }
 
+// The same for rows of an even number of words, which the lanes would write into the same few LDS banks:
+// the tile's rows are R + 1 words apart, and the copy undoes the padding.
+template <int R>
+__device__ __forceinline__ void tile_store_padded_rows(float* __restrict__ dst, int P, const float* tile) {
+  __syncthreads();
+  const size_t base = (size_t)blockIdx.x * kBlock * R;
+  const int rows = min(kBlock, P - (int)blockIdx.x * kBlock);
+  for (int e = threadIdx.x; e < rows * R; e += kBlock) dst[base + e] = tile[(e / R) * (R + 1) + e % R];
+}
+
 // Activations of the model's raw parameters (scene/gaussian_model.py:33-41,95-118):
 // scale = exp(raw), opacity = sigmoid(raw), rotation = raw / max(|raw|, 1e-12).
 __device__ __forceinline__ float sigmoidf(float x) { return 1.0f / (1.0f + expf(-x)); }
@@ -423,7 +433,7 @@ __device__ __forceinline__ void store_f4(float* dst, const float* v) {
 
 template <int D>
 __global__ void __launch_bounds__(kBlock, 4) preprocess_bwd_kernel(BwdArgs a) {
-  extern __shared__ float rest_tile[];   // raw mode only: the block's rows of the _features_rest gradient
+  extern __shared__ float rest_tile[];   // the block's rows of the SH gradient (raw mode: of _features_rest), stored coalesced
   const int i = blockIdx.x * kBlock + threadIdx.x;
   const bool valid = i < a.P;
   uint4 r3 = make_uint4(0u, 0u, 0u, 0u);
@@ -642,6 +652,22 @@ __global__ void __launch_bounds__(kBlock, 4) preprocess_bwd_kernel(BwdArgs a) {
       float* dc = a.dL_dshs + (size_t)i * 3;
       dc[0] = dsh[0]; dc[1] = dsh[1]; dc[2] = dsh[2];
     }
+  } else if (a.dL_dshs) {
+    // the (P, M, 3) gradient the same way: written row by row from the lanes it would go out as 16-byte
+    // pieces of 64 different rows per store instruction
+    const int R = a.M * 3;
+    if (R == 48) {
+      float* row = rest_tile + threadIdx.x * 49;
+#pragma unroll
+      for (int k = 0; k < 48; k++) row[k] = dsh[k];
+      tile_store_padded_rows<48>(a.dL_dshs, a.P, rest_tile);
+    } else {
+      float* row = rest_tile + threadIdx.x * R;
+#pragma unroll
+      for (int k = 0; k < 48; k++)
+        if (k < R) row[k] = dsh[k];
+      tile_store_rows(a.dL_dshs, a.P, R, rest_tile);
+    }
   }
   if (!valid) return;
   a.dL_dmeans3D[3 * (size_t)i] = dmean[0];
@@ -651,17 +677,6 @@ __global__ void __launch_bounds__(kBlock, 4) preprocess_bwd_kernel(BwdArgs a) {
   a.dL_dmeans2D[3 * (size_t)i + 1] = g0.y;
   a.dL_dmeans2D[3 * (size_t)i + 2] = 0.f;
   a.dL_dopacities[i] = dopac;
-  if (!a.dL_dshs_rest && a.dL_dshs) {
-    float* dst = a.dL_dshs + (size_t)i * a.M * 3;
-    if (a.M == 16) {
-      store_f4<48>(dst, dsh);
-    } else {
-      // static indices only: a runtime-indexed dsh[] would live in scratch memory
-#pragma unroll
-      for (int k = 0; k < 48; k++)
-        if (k < a.M * 3) dst[k] = dsh[k];
-    }
-  }
   if (a.dL_dcolors) {
     a.dL_dcolors[3 * (size_t)i] = g1.z;
     a.dL_dcolors[3 * (size_t)i + 1] = g1.w;
@@ -769,11 +784,12 @@ extern "C" int gsr_preprocess_bwd(int P, int D, int M, const float* means3D, con
   hipStream_t st = (hipStream_t)stream;
   dim3 grid(gsr::div_up(P, kBlock)), block(kBlock);
   const int d = shs ? D : 0;
+  const size_t lds = shs ? (size_t)kBlock * (M * 3 + 1) * sizeof(float) : 0;     // the block's tile of the SH gradient
   switch (d) {
-    case 0: hipLaunchKernelGGL(preprocess_bwd_kernel<0>, grid, block, 0, st, a); break;
-    case 1: hipLaunchKernelGGL(preprocess_bwd_kernel<1>, grid, block, 0, st, a); break;
-    case 2: hipLaunchKernelGGL(preprocess_bwd_kernel<2>, grid, block, 0, st, a); break;
-    default: hipLaunchKernelGGL(preprocess_bwd_kernel<3>, grid, block, 0, st, a); break;
+    case 0: hipLaunchKernelGGL(preprocess_bwd_kernel<0>, grid, block, lds, st, a); break;
+    case 1: hipLaunchKernelGGL(preprocess_bwd_kernel<1>, grid, block, lds, st, a); break;
+    case 2: hipLaunchKernelGGL(preprocess_bwd_kernel<2>, grid, block, lds, st, a); break;
+    default: hipLaunchKernelGGL(preprocess_bwd_kernel<3>, grid, block, lds, st, a); break;
   }
   return gsr::check_launch("preprocess_bwd");
 }
@@ -838,7 +854,8 @@ extern "C" int gsr_preprocess_bwd_raw(int P, int D, int n_rest, const float* xyz
             dL_dfeatures_dc, nullptr, dL_dscaling_raw, dL_drotation_raw, nullptr};
   hipStream_t st = (hipStream_t)stream;
   dim3 grid(gsr::div_up(P, kBlock)), block(kBlock);
-  const size_t lds = split ? (size_t)kBlock * n_rest * 3 * sizeof(float) : 0;
+  // the block's tile of the SH gradient: the rows of features_rest, or of features_dc when there is no rest tensor
+  const size_t lds = (size_t)kBlock * (split ? n_rest * 3 : 3 + 1) * sizeof(float);
   switch (D) {
     case 0: hipLaunchKernelGGL(preprocess_bwd_kernel<0>, grid, block, lds, st, a); break;
     case 1: hipLaunchKernelGGL(preprocess_bwd_kernel<1>, grid, block, lds, st, a); break;

@@ -56,8 +56,9 @@ def test_fused_adam_against_cpu_restatement_and_errors():
         adam_ref.adam_step(p, gr.numpy(), m, v, 0.01, step)
     torch.cuda.synchronize()
     assert np.abs(ours["a"].cpu().numpy() - p).max() < 2e-6
-    with pytest.raises(ValueError):
-        GaussianAdam({"a": p0.clone()}, {"a": 0.01})           # CPU tensor: no fallback
+    cpu = GaussianAdam({"a": p0.clone()}, {"a": 0.01})         # a CPU tensor can be kept (state bookkeeping) ...
+    with pytest.raises(ValueError, match="GPU only"):
+        cpu.step({"a": torch.zeros_like(p0)})                   # ... but not stepped: no fallback
     with pytest.raises(ValueError):
         opt.step({"a": gr[:10].cuda()})
 
