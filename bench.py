@@ -106,8 +106,10 @@ def limits(kernel, ms, alg_bytes, counters, source):
     """How close one kernel runs to each of its three candidate limits, from its duration and the committed
     counters of the same workload.  hbm: measured HBM bytes over the 8 TB/s peak.  valu: vector
     wave-instructions x 2 issue cycles (a wave64 instruction occupies a SIMD-32 for two cycles) over the
-    cycles of the 1024 SIMDs.  lds: cycles the LDS pipes were busy issuing (SQ_ACTIVE_INST_LDS, which counts
-    quad-cycles) over the cycles of the 256 CUs' LDS units.  The last two assume the 2.4 GHz peak clock."""
+    cycles of the 1024 SIMDs.  lds: cycles the LDS arrays were busy (SQ_LDS_IDX_ACTIVE, bank conflicts
+    included) over the cycles of the 256 CUs' LDS units.  The last two assume the 2.4 GHz peak clock, so they
+    are lower bounds.  A kernel none of whose fractions is near 1 is bound by latency and instruction
+    dependencies at the occupancy it runs at, not by any one of these."""
     t = ms * 1e-3
     out = {"algorithmic_bytes": alg_bytes, "source": source}
     traffic = counters.get("bytes_per_launch", {}).get(kernel)
@@ -123,15 +125,16 @@ def limits(kernel, ms, alg_bytes, counters, source):
     if lds:
         out["lds_wave_instructions"] = lds.get("wave_instructions")
         out["lds_bank_conflict_cycles"] = lds.get("bank_conflict_cycles")
-        if lds.get("active_quad_cycles"):
-            fr["lds_issue"] = 4.0 * lds["active_quad_cycles"] / (CUS * t * CLOCK_HZ)
+        if lds.get("idx_active_cycles"):
+            fr["lds_array"] = lds["idx_active_cycles"] / (CUS * t * CLOCK_HZ)
     out["fractions_of_peak"] = {k: round(v, 3) for k, v in fr.items()}
     real = {k: v for k, v in fr.items() if k != "hbm_algorithmic"}
     if real:
         top = max(real, key=real.get)
         out["limited_by"] = {"hbm_measured": "HBM bandwidth", "valu_issue": "vector-instruction issue",
-                             "lds_issue": "the LDS pipe"}[top] + f" ({real[top]:.0%} of its peak; the others: " + \
-            ", ".join(f"{k} {v:.0%}" for k, v in real.items() if k != top) + ")"
+                             "lds_array": "the LDS"}[top] + f" is the busiest unit ({real[top]:.0%} of its peak; " + \
+            ", ".join(f"{k} {v:.0%}" for k, v in real.items() if k != top) + ")" + \
+            ("" if real[top] > 0.8 else "; none is saturated: latency and instruction dependencies at 8 waves per SIMD")
     return out
 
 

@@ -28,7 +28,7 @@ def means(directory):
     for f in glob.glob(os.path.join(directory, "**", "*counter_collection.csv"), recursive=True):
         for r in csv.DictReader(open(f)):
             k = short(r["Kernel_Name"])
-            stage = next((v for p, v in STAGE_OF.items() if k.startswith(p)), None)
+            stage = next((v for p, v in STAGE_OF.items() if p in k), None)
             if stage:
                 a = acc[stage][r["Counter_Name"]]
                 a[0] += float(r["Counter_Value"])
