@@ -39,8 +39,11 @@ GRAD_WORDS = 16
 # the bounding box of the Gaussian's alpha >= 1/255 ellipse does not reach: the same images, radii and
 # gradients from lists a third shorter (render 2-3 % faster at 1M-6M Gaussians).
 REFERENCE_LISTS = os.environ.get("GSR_SHORT_LISTS", "0") in ("", "0")
-# GSR_NO_OVERLAP=1 clears the backward's accumulator on the caller's stream (A/B runs, debugging)
-_OVERLAP = os.environ.get("GSR_NO_OVERLAP", "0") in ("", "0")
+# GSR_OVERLAP=1 clears the backward's accumulator on a second stream beside the depth sort and the list
+# builder instead of on the caller's stream right before the blend backward.  Off by default: kernels of
+# two streams do not hide beside each other here, the binning slows down by more than the 13 us the fill
+# takes (1M Gaussians: train step 0.905 ms without, 0.92 ms with; tools/exp_overlap.py).
+_OVERLAP = os.environ.get("GSR_OVERLAP", "0") not in ("", "0")
 # The forward is ONE call into the library (gsr_forward) unless GSR_STAGED=1 or a stage timer is installed;
 # then it is the sequence of stage calls, with the same results bit for bit.
 SINGLE_CALL = os.environ.get("GSR_STAGED", "0") in ("", "0")
