@@ -601,28 +601,47 @@ __global__ void __launch_bounds__(kScanBlock) scan2_kernel(Grid g, const uint32_
 }
 
 // After the level-3 counting sweep: positions in point_list and the tile ranges,
-// [start, end) per tile, (0,0) for empty tiles.
-__global__ void __launch_bounds__(kScanBlock) scan3_kernel(Grid g, const uint32_t* piece_first3, uint32_t* counts,
-                                                           uint32_t* ranges) {
+// [start, end) per tile, (0,0) for empty tiles.  The tiles of a cell come from two dependent loads each
+// (the cell's pieces, then the scanned counts at the ends of the tile's run of pieces); a thread's tiles are
+// handled kTilesAtOnce at a time with the loads of all of them in flight together, not one round trip
+// after the other.
+constexpr int kTilesAtOnce = 4;
+
+__global__ void __launch_bounds__(kScanBlock) scan3_kernel(Grid g, const uint32_t* __restrict__ piece_first3,
+                                                           uint32_t* __restrict__ counts, uint32_t* __restrict__ ranges) {
   __shared__ uint32_t s_wave[kScanBlock / 64];
   const uint32_t parents = (uint32_t)g.cells();
   const uint32_t slots = piece_first3[parents] * kSuper;
   const uint32_t total = block_scan_inplace(counts, slots, s_wave);
   __syncthreads();
-  for (uint32_t q = threadIdx.x; q < parents * kSuper; q += kScanBlock) {
-    const uint32_t c = q / kSuper, f = q % kSuper;
-    const uint32_t x = (c % g.sx) * kSuper + f, y = c / g.sx;
-    if (x >= (uint32_t)g.gx) continue;
-    const uint32_t pf0 = piece_first3[c], np = piece_first3[c + 1] - pf0;
-    uint32_t begin = 0u, end = 0u;
-    if (np) {
-      const uint32_t s0 = pf0 * kSuper + f * np;
-      begin = counts[s0];
-      end = s0 + np < slots ? counts[s0 + np] : total;
+  const uint32_t work = parents * kSuper;
+  for (uint32_t q0 = threadIdx.x; q0 < work; q0 += kTilesAtOnce * kScanBlock) {
+    uint32_t pf0[kTilesAtOnce], pf1[kTilesAtOnce];
+#pragma unroll
+    for (int k = 0; k < kTilesAtOnce; k++) {
+      const uint32_t q = q0 + k * kScanBlock, c = min(q, work - 1u) / kSuper;
+      pf0[k] = piece_first3[c];
+      pf1[k] = piece_first3[c + 1];
     }
-    const uint32_t t = y * g.gx + x;
-    ranges[2 * t] = end > begin ? begin : 0u;
-    ranges[2 * t + 1] = end > begin ? end : 0u;
+    uint32_t begin[kTilesAtOnce], end[kTilesAtOnce];
+#pragma unroll
+    for (int k = 0; k < kTilesAtOnce; k++) {
+      const uint32_t q = q0 + k * kScanBlock, f = q % kSuper, np = pf1[k] - pf0[k];
+      const uint32_t s0 = pf0[k] * kSuper + f * np;
+      const bool any = q < work && np != 0u;
+      begin[k] = any ? counts[s0] : 0u;
+      end[k] = !any ? 0u : (s0 + np < slots ? counts[s0 + np] : total);
+    }
+#pragma unroll
+    for (int k = 0; k < kTilesAtOnce; k++) {
+      const uint32_t q = q0 + k * kScanBlock;
+      if (q >= work) continue;
+      const uint32_t c = q / kSuper, f = q % kSuper;
+      const uint32_t x = (c % g.sx) * kSuper + f, y = c / g.sx;
+      if (x >= (uint32_t)g.gx) continue;
+      const uint32_t t = y * g.gx + x;
+      reinterpret_cast<uint2*>(ranges)[t] = end[k] > begin[k] ? make_uint2(begin[k], end[k]) : make_uint2(0u, 0u);
+    }
   }
 }
 
