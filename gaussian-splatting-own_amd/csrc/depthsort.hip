@@ -64,7 +64,17 @@ __device__ __forceinline__ uint32_t wave_incl_scan(uint32_t v) {
   return v;
 }
 
-__global__ void __launch_bounds__(256) sort_clear_kernel(uint32_t* __restrict__ words, size_t n) {
+// Clears the histograms, control words and look-back states.  With mirror_dst, the first workgroup also
+// copies eight words (the list sizes and the carried status of the preprocess) to host-visible memory: the
+// read-back then costs no copy command between the preprocess and the sort, only this kernel's own stores,
+// which are pushed out to the host before the wave ends.
+__global__ void __launch_bounds__(256) sort_clear_kernel(uint32_t* __restrict__ words, size_t n,
+                                                         const uint32_t* __restrict__ mirror_src,
+                                                         uint32_t* __restrict__ mirror_dst) {
+  if (mirror_dst != nullptr && blockIdx.x == 0 && threadIdx.x < 8) {
+    mirror_dst[threadIdx.x] = mirror_src[threadIdx.x];
+    __threadfence_system();
+  }
   for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (size_t)gridDim.x * 256) words[i] = 0u;
 }
 
@@ -382,7 +392,8 @@ size_t depth_sort_bytes(int P) { return P > 0 ? layout((uint32_t)P).total : 256;
 
 // sorted_vals[0 .. visible) = the values of the keys != 0xFFFFFFFF in ascending key order, equal
 // keys in input order; the rest of sorted_vals is left untouched.
-int depth_sort(int P, const uint32_t* keys, const uint64_t* vals, uint64_t* sorted_vals, void* scratch, hipStream_t st) {
+int depth_sort(int P, const uint32_t* keys, const uint64_t* vals, uint64_t* sorted_vals, void* scratch, hipStream_t st,
+               const SortMirror* mirror) {
   const Layout L = layout((uint32_t)P);
   char* base = (char*)scratch;
   uint32_t* hist = (uint32_t*)base;
@@ -393,7 +404,12 @@ int depth_sort(int P, const uint32_t* keys, const uint64_t* vals, uint64_t* sort
   u64* va = (u64*)(base + L.vals_a);
   u64* vb = (u64*)(base + L.vals_b);
   const unsigned clear_blocks = (unsigned)((L.clear_words + 1023) / 1024 < 1024 ? (L.clear_words + 1023) / 1024 : 1024);
-  hipLaunchKernelGGL(sort_clear_kernel, dim3(clear_blocks), dim3(256), 0, st, hist, L.clear_words);
+  hipLaunchKernelGGL(sort_clear_kernel, dim3(clear_blocks), dim3(256), 0, st, hist, L.clear_words,
+                     mirror ? mirror->src : nullptr, mirror ? mirror->dst : nullptr);
+  if (mirror && mirror->event) {
+    const hipError_t e = hipEventRecord(mirror->event, st);
+    if (e != hipSuccess) return gsr::fail(GSR_E_LAUNCH, "depth_sort: event: %s", hipGetErrorString(e));
+  }
   const unsigned hist_wanted = ((unsigned)P + 4095u) / 4096u;
   // 512: measured against 32 .. 2048 at 1M and 6M keys (fewer blocks serialise the LDS counting, more only add flush atomics)
   const unsigned hist_blocks = hist_wanted < 512u ? hist_wanted : 512u;
@@ -497,5 +513,5 @@ extern "C" int gsr_bin_sort_static(int P, const uint32_t* depth_keys, const uint
   GSR_REQUIRE(depth_keys && sort_vals && sorted_vals, "bin_sort_static: null pointer");
   // depth_sort clears the look-back words, tickets, histograms and the error word with a kernel of its own
   // before it uses them: whatever the previous call left in the array does not matter
-  return gsr::depth_sort(P, depth_keys, sort_vals, sorted_vals, ptr, (hipStream_t)stream);
+  return gsr::depth_sort(P, depth_keys, sort_vals, sorted_vals, ptr, (hipStream_t)stream, nullptr);
 }

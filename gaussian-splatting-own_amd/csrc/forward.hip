@@ -4,6 +4,8 @@
 // are theirs bit for bit.  The point of it is the host side: one transition into native code per render
 // instead of five, and one workspace instead of a dozen buffers, which is what a render of 100k
 // Gaussians spends as much time on as on its kernels.
+#include <cstdlib>
+
 #include "gsr_common.h"
 
 namespace {
@@ -89,11 +91,21 @@ extern "C" int gsr_forward(const GsrForwardArgs* a, gsr_resize_fn resize, void* 
     if (rc) return rc;
     if ((rc = checkpoint("preprocess"))) return rc;
     if (a->after_preprocess) a->after_preprocess(a->hook_ctx);
-    // the list sizes (and the carried status word) travel to the host while the GPU sorts by depth
-    hipError_t e = hipMemcpyAsync(a->h_totals, w.totals, 8 * sizeof(uint32_t), hipMemcpyDeviceToHost, st);
-    if (e == hipSuccess) e = hipEventRecord((hipEvent_t)a->event, st);
-    if (e != hipSuccess) return hip_fail("read-back of the list sizes", e);
-    rc = gsr_bin_sort(P, w.depth_keys, w.sort_vals, w.sorted_vals, w.sort_scratch, w.sort_bytes, stream);
+    // The list sizes (and the carried status word) travel to the host while the GPU sorts by depth.  When
+    // the landing buffer is pinned memory the GPU can address, the sort's first kernel stores them there
+    // itself; otherwise a copy command goes ahead of the sort.
+    static const bool copy_always = getenv("GSR_COPY_READBACK") != nullptr;   // for measurements of the difference
+    void* landing = nullptr;
+    hipError_t e = copy_always ? hipErrorInvalidValue : hipHostGetDevicePointer(&landing, a->h_totals, 0);
+    if (e != hipSuccess) {
+      (void)hipGetLastError();
+      landing = nullptr;
+      e = hipMemcpyAsync(a->h_totals, w.totals, 8 * sizeof(uint32_t), hipMemcpyDeviceToHost, st);
+      if (e == hipSuccess) e = hipEventRecord((hipEvent_t)a->event, st);
+      if (e != hipSuccess) return hip_fail("read-back of the list sizes", e);
+    }
+    const gsr::SortMirror mirror{w.totals, (uint32_t*)landing, (hipEvent_t)a->event};
+    rc = gsr::depth_sort(P, w.depth_keys, w.sort_vals, w.sorted_vals, w.sort_scratch, st, landing ? &mirror : nullptr);
     if (rc) return rc;
     sort_error = gsr_bin_sort_error_word(w.sort_scratch);
     if (a->debug && (rc = gsr_bin_sort_status(P, w.sort_scratch, w.sort_bytes, stream))) return rc;

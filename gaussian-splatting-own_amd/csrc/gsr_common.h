@@ -71,8 +71,15 @@ int launch_totals_final(int blocks, const uint32_t* partials, const uint32_t* st
 // key is not 0xFFFFFFFF, by ascending key, equal keys in input order.  scratch: depth_sort_bytes(P)
 // bytes, 256-byte aligned.
 size_t depth_sort_bytes(int P);
+// Optional rider of the sort's first kernel: eight words copied from device memory (src) to host-visible
+// memory (dst, a device-side address of pinned host memory), and an event recorded right behind that kernel.
+struct SortMirror {
+  const uint32_t* src;
+  uint32_t* dst;
+  hipEvent_t event;
+};
 int depth_sort(int P, const uint32_t* keys, const uint64_t* vals, uint64_t* sorted_vals, void* scratch,
-               hipStream_t stream);
+               hipStream_t stream, const SortMirror* mirror = nullptr);
 // Waits for the stream, then GSR_OK or GSR_E_SORT for the sort that last used this scratch.
 int depth_sort_status(const void* scratch, hipStream_t stream);
 // Device address of the word that is non-zero after a sort that gave up (inside its scratch).

@@ -246,7 +246,10 @@ int gsr_blend_fwd(int W, int H, const uint32_t* ranges, const uint32_t* point_li
  * radii, optionally visible), one WORKSPACE of gsr_forward_workspace_bytes(P, W, H)
  * bytes (256-byte aligned) for everything else whose size is known up front, a
  * page-locked host buffer of 8 words and an event (gsr_event_create) for the
- * read-back, and optionally a status word (see gsr_bin_lists).  Once the list
+ * read-back, and optionally a status word (see gsr_bin_lists).  When the GPU can
+ * address the host buffer (hipHostMalloc / torch pinned memory: the usual case)
+ * the depth sort's first kernel stores the eight words there itself and no copy
+ * command is issued; pageable memory gets an ordinary copy.  Once the list
  * sizes have arrived, `resize(resize_ctx, bytes)` is called ONCE for the memory
  * of the tile lists and the list builder's scratch (256-byte aligned device
  * memory, or NULL to fail); it must stay valid as long as the lists are used.
