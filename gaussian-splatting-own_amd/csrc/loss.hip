@@ -6,15 +6,24 @@
 // The reference evaluates SSIM with five grouped 11x11 convolutions and a dozen
 // elementwise kernels over (3,H,W); at 1080p that is several milliseconds of
 // library convolutions around a 25 MB image.  Here one kernel per direction
-// does it from LDS: a 32x32 output tile loads its 42x42 halo of both images
-// once, filters the five moments separably (horizontal, then vertical), and
-// forms the SSIM value plus the three partial derivatives the backward needs;
-// the backward filters those three maps the same way.  Both filter passes are
-// register-blocked: a thread produces four consecutive outputs along the filter
-// direction from fourteen inputs it holds in registers, so that an output costs
-// 3.5 LDS reads per moment instead of 11 (the passes are LDS-read-bound
-// otherwise).  HBM traffic: forward reads 8 B and writes 12 B per pixel-channel,
-// backward reads 20 B and writes 4 B.
+// does it on 32x32 output tiles with their 42x42 halo, separably (horizontal
+// pass into LDS, then vertical).  The forward filters four moments (the two
+// means, E[x^2] + E[y^2] (SSIM uses the variances only as their sum) and
+// E[xy]) and forms the SSIM value plus the three partial derivatives the
+// backward needs; the backward filters those three maps the same way.  Both
+// filter passes are register-blocked: a thread produces four consecutive
+// outputs along the filter direction from fourteen inputs it holds in
+// registers, so that an output costs 3.5 reads per moment instead of 11.
+// The forward's horizontal pass reads its inputs straight from global memory
+// (14 consecutive floats per task; the overlap between tasks is the L1's
+// business): staging the halo of both images in LDS first cost a barrier and
+// 15 KB per workgroup, and the kernel is bound by how well the workgroups of a
+// CU overlap one's arithmetic with another's loads and barriers (0.061 -> 0.050
+// ms at 1080p).  The backward keeps the staged halo with the next tile's loads
+// prefetched into registers: the direct form is no faster there (three maps,
+// hence three load latencies in a row or too many registers).  HBM traffic:
+// forward reads 8 B and writes 12 B per pixel-channel, backward reads 20 B and
+// writes 4 B.
 #include "gsr_common.h"
 
 namespace {
@@ -24,13 +33,13 @@ constexpr int kTaps = 2 * kR + 1;
 constexpr int kTX = 32, kTY = 32;        // output tile
 constexpr int kIW = kTX + 2 * kR;        // 42 input columns
 constexpr int kIH = kTY + 2 * kR;        // 42 input rows
-constexpr int kIS = 44;                  // LDS row stride of an input tile: a multiple of 4 floats
+constexpr int kIS = 44;                  // LDS row stride of a staged input tile: a multiple of 4 floats
 constexpr int kOut = 4;                  // outputs per thread along the filter direction
 constexpr int kNeed = kOut + 2 * kR;     // 14 inputs for them
 constexpr int kHTasks = kIH * (kTX / kOut);          // horizontal pass: 42 rows x 8 column groups
 constexpr int kVTasks = kTX * (kTY / kOut);          // vertical pass: 32 columns x 8 row groups
-static_assert(kVTasks == 256, "the vertical pass gives every thread of the block exactly one task");
 constexpr int kLoads = (kIH * kIW + 255) / 256;      // halo elements per thread
+static_assert(kVTasks == 256, "the vertical pass gives every thread of the block exactly one task");
 
 struct Window { float w[kTaps]; };
 
@@ -46,6 +55,29 @@ Window make_window() {
 
 constexpr float kC1 = 0.01f * 0.01f;
 constexpr float kC2 = 0.03f * 0.03f;
+
+// 14 consecutive floats of row gy of an (H,W) plane starting at column gx0, zero outside the image.
+// Any 4-byte alignment: the vector type says so, and global loads of 16 bytes need no more.
+typedef float float4u __attribute__((ext_vector_type(4), aligned(4)));
+typedef float float2u __attribute__((ext_vector_type(2), aligned(4)));
+
+__device__ __forceinline__ void load14(const float* __restrict__ plane, int H, int W, int gy, int gx0, float* a) {
+  if (gy < 0 || gy >= H) {
+#pragma unroll
+    for (int i = 0; i < kNeed; i++) a[i] = 0.f;
+  } else if (gx0 >= 0 && gx0 + kNeed <= W) {
+    const float* p = plane + (size_t)gy * W + gx0;
+    const float4u q0 = *reinterpret_cast<const float4u*>(p), q1 = *reinterpret_cast<const float4u*>(p + 4),
+                  q2 = *reinterpret_cast<const float4u*>(p + 8);
+    const float2u q3 = *reinterpret_cast<const float2u*>(p + 12);
+    a[0] = q0.x; a[1] = q0.y; a[2] = q0.z; a[3] = q0.w; a[4] = q1.x; a[5] = q1.y; a[6] = q1.z; a[7] = q1.w;
+    a[8] = q2.x; a[9] = q2.y; a[10] = q2.z; a[11] = q2.w; a[12] = q3.x; a[13] = q3.y;
+  } else {
+    const float* p = plane + (size_t)gy * W;
+#pragma unroll
+    for (int i = 0; i < kNeed; i++) a[i] = (gx0 + i >= 0 && gx0 + i < W) ? p[gx0 + i] : 0.f;
+  }
+}
 
 // 14 consecutive floats starting at a 16-byte aligned LDS address
 __device__ __forceinline__ void read14(const float* p, float* a) {
@@ -107,63 +139,58 @@ __device__ __forceinline__ TileWalk make_walk(int H, int W, int C) {
 __global__ void __launch_bounds__(256) loss_fwd_kernel(int H, int W, int C, const float* __restrict__ img,
                                                        const float* __restrict__ gt, Window win,
                                                        float* __restrict__ dmaps, float* __restrict__ partial) {
-  __shared__ __align__(16) float sx[kIH * kIS], sy[kIH * kIS];
-  __shared__ __align__(16) float hm[5][kIH * kTX];      // x, y, xx, yy, xy after the horizontal pass
+  // x, y, xx + yy, xy after the horizontal pass
+  __shared__ __align__(16) float hm[4][kIH * kTX];
   __shared__ float red[2][4];
   const size_t plane = (size_t)H * W;
   const TileWalk walk = make_walk(H, W, C);
-  const bool vtask = true;
   const int lx = threadIdx.x % kTX, ly = (threadIdx.x / kTX) * kOut;
   float l1 = 0.f, ss = 0.f;
-  Halo px, py;
-  int c, bx, by;
-  if (walk.first < walk.last) {
-    walk.decode(walk.first, c, bx, by);
-    fetch_halo(img + c * plane, H, W, bx * kTX - kR, by * kTY - kR, px);
-    fetch_halo(gt + c * plane, H, W, bx * kTX - kR, by * kTY - kR, py);
-  }
   for (int t = walk.first; t < walk.last; t += walk.step) {
+    int c, bx, by;
     walk.decode(t, c, bx, by);
-    stash_halo(px, sx);
-    stash_halo(py, sy);
-    __syncthreads();
-    if (t + walk.step < walk.last) {
-      int nc, nbx, nby;
-      walk.decode(t + walk.step, nc, nbx, nby);
-      fetch_halo(img + nc * plane, H, W, nbx * kTX - kR, nby * kTY - kR, px);
-      fetch_halo(gt + nc * plane, H, W, nbx * kTX - kR, nby * kTY - kR, py);
-    }
-
+    const float* const xc = img + c * plane;
+    const float* const yc = gt + c * plane;
     for (int k = threadIdx.x; k < kHTasks; k += 256) {
       const int r = k / (kTX / kOut), q = (k % (kTX / kOut)) * kOut;
-      float a[kNeed], b[kNeed], o[5][kOut];
-      read14(sx + r * kIS + q, a);
-      read14(sy + r * kIS + q, b);
+      float a[kNeed], b[kNeed], o[4][kOut];
+      load14(xc, H, W, by * kTY - kR + r, bx * kTX - kR + q, a);
+      load14(yc, H, W, by * kTY - kR + r, bx * kTX - kR + q, b);
 #pragma unroll
-      for (int m = 0; m < 5; m++)
+      for (int m = 0; m < 4; m++)
 #pragma unroll
         for (int j = 0; j < kOut; j++) o[m][j] = 0.f;
 #pragma unroll
       for (int i = 0; i < kNeed; i++) {
-        const float x = a[i], y = b[i], xx = x * x, yy = y * y, xy = x * y;
+        const float x = a[i], y = b[i], sq = fmaf(x, x, y * y), xy = x * y;
 #pragma unroll
         for (int j = 0; j < kOut; j++) {
           const int kk = i - j;
           if (kk >= 0 && kk < kTaps) {
             const float w = win.w[kk];
-            o[0][j] += w * x; o[1][j] += w * y; o[2][j] += w * xx; o[3][j] += w * yy; o[4][j] += w * xy;
+            o[0][j] += w * x; o[1][j] += w * y; o[2][j] += w * sq; o[3][j] += w * xy;
           }
         }
       }
 #pragma unroll
-      for (int m = 0; m < 5; m++)
+      for (int m = 0; m < 4; m++)
         *reinterpret_cast<float4*>(&hm[m][r * kTX + q]) = make_float4(o[m][0], o[m][1], o[m][2], o[m][3]);
     }
     __syncthreads();
 
-    float acc[5][kOut];
+    // this thread's own pixels of both images, for the L1 term
+    const int gx = bx * kTX + lx;
+    float xs[kOut], ys[kOut];
 #pragma unroll
-    for (int m = 0; m < 5; m++) {
+    for (int j = 0; j < kOut; j++) {
+      const int gy = by * kTY + ly + j;
+      const bool in = gx < W && gy < H;
+      xs[j] = in ? xc[(size_t)gy * W + gx] : 0.f;
+      ys[j] = in ? yc[(size_t)gy * W + gx] : 0.f;
+    }
+    float acc[4][kOut];
+#pragma unroll
+    for (int m = 0; m < 4; m++) {
       float v[kNeed];
 #pragma unroll
       for (int i = 0; i < kNeed; i++) v[i] = hm[m][(ly + i) * kTX + lx];
@@ -175,15 +202,14 @@ __global__ void __launch_bounds__(256) loss_fwd_kernel(int H, int W, int C, cons
         acc[m][j] = s;
       }
     }
-    const int gx = bx * kTX + lx;
 #pragma unroll
     for (int j = 0; j < kOut; j++) {
       const int gy = by * kTY + ly + j;
-      if (vtask && gx < W && gy < H) {
-        const float mu1 = acc[0][j], mu2 = acc[1][j], exx = acc[2][j], eyy = acc[3][j], exy = acc[4][j];
-        const float mu1_sq = mu1 * mu1, mu2_sq = mu2 * mu2, mu12 = mu1 * mu2;
-        const float s1 = exx - mu1_sq, s2 = eyy - mu2_sq, s12 = exy - mu12;
-        const float A = mu1_sq + mu2_sq + kC1, B = s1 + s2 + kC2, Cc = 2.0f * mu12 + kC1, D = 2.0f * s12 + kC2;
+      if (gx < W && gy < H) {
+        const float mu1 = acc[0][j], mu2 = acc[1][j], esq = acc[2][j], exy = acc[3][j];   // esq = E[x^2] + E[y^2]
+        const float mu_sq = mu1 * mu1 + mu2 * mu2, mu12 = mu1 * mu2;
+        const float s12 = exy - mu12;
+        const float A = mu_sq + kC1, B = (esq - mu_sq) + kC2, Cc = 2.0f * mu12 + kC1, D = 2.0f * s12 + kC2;
         const float invA = 1.0f / A, invB = 1.0f / B;
         const float S = Cc * D * invA * invB;
         // partial derivatives of S w.r.t. (sigma1^2, sigma12) and the total derivative w.r.t. mu1
@@ -196,10 +222,10 @@ __global__ void __launch_bounds__(256) loss_fwd_kernel(int H, int W, int C, cons
         dmaps[cs + o] = dS_ds1;
         dmaps[2 * cs + o] = dS_ds12;
         ss += S;
-        l1 += fabsf(sx[(ly + j + kR) * kIS + lx + kR] - sy[(ly + j + kR) * kIS + lx + kR]);
+        l1 += fabsf(xs[j] - ys[j]);
       }
     }
-    __syncthreads();   // the next tile overwrites sx, sy, hm
+    __syncthreads();   // the next tile overwrites hm
   }
   // block sums -> one (l1, ssim) pair per block, summed later in a fixed order
 #pragma unroll
@@ -328,7 +354,7 @@ int loss_blocks(int C, int H, int W, int per_cu) {
   const int cap = 256 * per_cu;
   return tiles < cap ? tiles / 8 * 8 : cap;
 }
-constexpr int kFwdPerCu = 3, kBwdPerCu = 4;   // resident blocks per CU (LDS-limited)
+constexpr int kFwdPerCu = 5, kBwdPerCu = 4;   // resident blocks per CU (registers forward, LDS backward)
 
 }  // namespace
 
