@@ -571,9 +571,27 @@ __global__ void __launch_bounds__(kScanBlock) scan1_kernel(Grid g, Guard guard, 
 }
 
 // After the level-2 counting sweep: positions, the cell lists (row-major cell ids), the level-3 pieces.
+// A one-block scan leaves the other 255 CUs idle for ten microseconds.  A caller's zero-fill can ride along:
+// workgroups 1 .. gridDim.x-1 of the launch clear `vecs` 16-byte words and leave, workgroup 0 scans.
+struct RiderFill {
+  uint4* at;
+  size_t vecs;
+};
+
+__device__ __forceinline__ void rider_fill(const RiderFill& f) {
+  const size_t stride = (size_t)(gridDim.x - 1) * kScanBlock;
+  for (size_t i = (size_t)(blockIdx.x - 1) * kScanBlock + threadIdx.x; i < f.vecs; i += stride) f.at[i] = make_uint4(0u, 0u, 0u, 0u);
+}
+
+inline unsigned rider_blocks(size_t vecs) {   // enough workgroups of 1024 threads for four stores per thread, at most 2 per CU
+  const size_t want = (vecs + 4 * kScanBlock - 1) / (4 * kScanBlock);
+  return (unsigned)(want < 512 ? want : 512);
+}
+
 __global__ void __launch_bounds__(kScanBlock) scan2_kernel(Grid g, const uint32_t* piece_first2, uint32_t* counts,
                                                            uint32_t* list_start, uint32_t* list_len,
-                                                           uint32_t* piece_first, uint4* desc) {
+                                                           uint32_t* piece_first, uint4* desc, RiderFill fill) {
+  if (blockIdx.x > 0) { rider_fill(fill); return; }
   __shared__ uint32_t s_wave[kScanBlock / 64];
   __shared__ uint32_t s_first[kFirstLds];
   const uint32_t parents = (uint32_t)g.supercells();
@@ -608,7 +626,9 @@ __global__ void __launch_bounds__(kScanBlock) scan2_kernel(Grid g, const uint32_
 constexpr int kTilesAtOnce = 4;
 
 __global__ void __launch_bounds__(kScanBlock) scan3_kernel(Grid g, const uint32_t* __restrict__ piece_first3,
-                                                           uint32_t* __restrict__ counts, uint32_t* __restrict__ ranges) {
+                                                           uint32_t* __restrict__ counts, uint32_t* __restrict__ ranges,
+                                                           RiderFill fill) {
+  if (blockIdx.x > 0) { rider_fill(fill); return; }
   __shared__ uint32_t s_wave[kScanBlock / 64];
   const uint32_t parents = (uint32_t)g.cells();
   const uint32_t slots = piece_first3[parents] * kSuper;
@@ -646,8 +666,7 @@ __global__ void __launch_bounds__(kScanBlock) scan3_kernel(Grid g, const uint32_
 }
 
 __global__ void __launch_bounds__(kBlock) zero_u32_kernel(uint32_t* p, size_t n) {
-  const size_t i = (size_t)blockIdx.x * kBlock + threadIdx.x;
-  if (i < n) p[i] = 0u;
+  for (size_t i = (size_t)blockIdx.x * kBlock + threadIdx.x; i < n; i += (size_t)gridDim.x * kBlock) p[i] = 0u;
 }
 
 // Optional: tile id of every sorted instance (from which the 64-bit sort keys are rebuilt).
@@ -729,18 +748,24 @@ extern "C" const uint32_t* gsr_bin_sort_error_word(const void* sort_scratch) {
   return sort_scratch ? gsr::depth_sort_error_word(sort_scratch) : nullptr;
 }
 
-extern "C" int gsr_bin_lists(int P, uint32_t V, uint32_t N, uint32_t E1, uint32_t E2, int W, int H,
-                             const uint64_t* sorted_vals, uint32_t* point_list, uint32_t* ranges,
-                             uint32_t* tile_ids_sorted, const uint32_t* sort_error, const uint32_t* totals,
-                             uint32_t* status, void* scratch, size_t scratch_bytes, void* stream) {
+int gsr::bin_lists(int P, uint32_t V, uint32_t N, uint32_t E1, uint32_t E2, int W, int H, const uint64_t* sorted_vals,
+                   uint32_t* point_list, uint32_t* ranges, uint32_t* tile_ids_sorted, const uint32_t* sort_error,
+                   const uint32_t* totals, uint32_t* status, void* scratch, size_t scratch_bytes, void* zero_fill,
+                   size_t zero_fill_bytes, hipStream_t st) {
   GSR_REQUIRE(P >= 0 && W > 0 && H > 0, "bin_lists: bad sizes");
   GSR_REQUIRE(ranges, "bin_lists: null ranges");
-  hipStream_t st = (hipStream_t)stream;
+  GSR_REQUIRE(zero_fill_bytes == 0 || (zero_fill && ((uintptr_t)zero_fill & 15) == 0 && zero_fill_bytes % 16 == 0),
+              "bin_lists: the zero-fill must be 16-byte aligned and a multiple of 16 bytes");
   const Grid g = make_grid(W, H);
   GSR_REQUIRE(g.sx <= 255 && g.sy <= 255, "bin_lists: image %dx%d too large", W, H);
+  // the rider is split between the two scans that have nothing else beside them
+  const size_t fill_vecs = zero_fill_bytes / 16;
+  const RiderFill fill2{(uint4*)zero_fill, fill_vecs / 2}, fill3{(uint4*)zero_fill + fill_vecs / 2, fill_vecs - fill_vecs / 2};
   if (N == 0 || V == 0 || P == 0) {
     hipLaunchKernelGGL(zero_u32_kernel, dim3((unsigned)gsr::div_up(2 * g.tiles(), kBlock)), dim3(kBlock), 0, st, ranges,
                        (size_t)2 * g.tiles());
+    if (fill_vecs)
+      hipLaunchKernelGGL(zero_u32_kernel, dim3(1024), dim3(kBlock), 0, st, (uint32_t*)zero_fill, fill_vecs * 4);
     return gsr::check_launch("bin_lists");
   }
   GSR_REQUIRE(sorted_vals && point_list && scratch, "bin_lists: null pointer");
@@ -782,9 +807,9 @@ extern "C" int gsr_bin_lists(int P, uint32_t V, uint32_t N, uint32_t E1, uint32_
   a.counts = (uint32_t*)(base + L.counts2);
   a.out64 = (u64*)(base + L.entries2);
   hipLaunchKernelGGL((partition_kernel<2, false>), dim3(L.max_pieces2), dim3(Level<2>::kThreads), 0, st, a);
-  hipLaunchKernelGGL(scan2_kernel, dim3(1), dim3(kScanBlock), 0, st, g, a.piece_first, a.counts,
+  hipLaunchKernelGGL(scan2_kernel, dim3(1 + rider_blocks(fill2.vecs)), dim3(kScanBlock), 0, st, g, a.piece_first, a.counts,
                      (uint32_t*)(base + L.list_start3), (uint32_t*)(base + L.list_len3),
-                     (uint32_t*)(base + L.piece_first3), (uint4*)(base + L.desc3));
+                     (uint32_t*)(base + L.piece_first3), (uint4*)(base + L.desc3), fill2);
   hipLaunchKernelGGL((partition_kernel<2, true>), dim3(L.max_pieces2), dim3(Level<2>::kThreads), 0, st, a);
   rc = gsr::check_launch("bin_lists: level 2");
   if (rc) return rc;
@@ -797,9 +822,18 @@ extern "C" int gsr_bin_lists(int P, uint32_t V, uint32_t N, uint32_t E1, uint32_
   a.out64 = nullptr;
   a.out32 = point_list;
   hipLaunchKernelGGL((partition_kernel<3, false>), dim3(L.max_pieces3), dim3(Level<3>::kThreads), 0, st, a);
-  hipLaunchKernelGGL(scan3_kernel, dim3(1), dim3(kScanBlock), 0, st, g, a.piece_first, a.counts, ranges);
+  hipLaunchKernelGGL(scan3_kernel, dim3(1 + rider_blocks(fill3.vecs)), dim3(kScanBlock), 0, st, g, a.piece_first, a.counts,
+                     ranges, fill3);
   hipLaunchKernelGGL((partition_kernel<3, true>), dim3(L.max_pieces3), dim3(Level<3>::kThreads), 0, st, a);
   if (tile_ids_sorted)
     hipLaunchKernelGGL(fill_tile_ids_kernel, dim3(g.tiles()), dim3(kBlock), 0, st, ranges, tile_ids_sorted);
   return gsr::check_launch("bin_lists: level 3");
+}
+
+extern "C" int gsr_bin_lists(int P, uint32_t V, uint32_t N, uint32_t E1, uint32_t E2, int W, int H,
+                             const uint64_t* sorted_vals, uint32_t* point_list, uint32_t* ranges,
+                             uint32_t* tile_ids_sorted, const uint32_t* sort_error, const uint32_t* totals,
+                             uint32_t* status, void* scratch, size_t scratch_bytes, void* stream) {
+  return gsr::bin_lists(P, V, N, E1, E2, W, H, sorted_vals, point_list, ranges, tile_ids_sorted, sort_error, totals, status,
+                        scratch, scratch_bytes, nullptr, 0, (hipStream_t)stream);
 }

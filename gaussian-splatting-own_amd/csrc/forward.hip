@@ -134,8 +134,9 @@ extern "C" int gsr_forward(const GsrForwardArgs* a, gsr_resize_fn resize, void* 
   out->point_list = got.take<uint32_t>(list_words * 4);
   out->tile_ids_sorted = a->keep_tile_ids ? got.take<uint32_t>(list_words * 4) : nullptr;
   void* lists_scratch = got.take<char>(lists_bytes);
-  int rc = gsr_bin_lists(P, V, N, E1, E2, W, H, w.sorted_vals, out->point_list, w.ranges, out->tile_ids_sorted, sort_error,
-                         P > 0 ? w.totals : nullptr, a->status, lists_scratch, lists_bytes, stream);
+  int rc = gsr::bin_lists(P, V, N, E1, E2, W, H, w.sorted_vals, out->point_list, w.ranges, out->tile_ids_sorted, sort_error,
+                          P > 0 ? w.totals : nullptr, a->status, lists_scratch, lists_bytes, a->zero_fill,
+                          a->zero_fill_bytes, st);
   if (rc) return rc;
   if ((rc = checkpoint("bin_lists"))) return rc;
   if (a->before_blend) a->before_blend(a->hook_ctx);

@@ -87,6 +87,13 @@ const uint32_t* depth_sort_error_word(const void* scratch);
 // Look-back steps a workgroup waits before it gives up (0 = the default); for tests of that path.
 void set_sort_spin_limit(uint32_t limit);
 
+// gsr_bin_lists with a rider: zero_fill_bytes of device memory at zero_fill (16-byte aligned, a multiple of
+// 16 bytes; 0 = none) are cleared by workgroups that run beside the list builder's one-block scan kernels.
+int bin_lists(int P, uint32_t V, uint32_t N, uint32_t E1, uint32_t E2, int W, int H, const uint64_t* sorted_vals,
+              uint32_t* point_list, uint32_t* ranges, uint32_t* tile_ids_sorted, const uint32_t* sort_error,
+              const uint32_t* totals, uint32_t* status, void* scratch, size_t scratch_bytes, void* zero_fill,
+              size_t zero_fill_bytes, hipStream_t stream);
+
 }  // namespace gsr
 
 #define GSR_REQUIRE(cond, ...)                                   \

@@ -44,6 +44,10 @@ REFERENCE_LISTS = os.environ.get("GSR_SHORT_LISTS", "0") in ("", "0")
 # two streams do not hide beside each other here, the binning slows down by more than the 13 us the fill
 # takes (1M Gaussians: train step 0.905 ms without, 0.92 ms with; tools/exp_overlap.py).
 _OVERLAP = os.environ.get("GSR_OVERLAP", "0") not in ("", "0")
+# In the single call the library clears that accumulator itself, with workgroups that ride on the list
+# builder's one-block scan kernels (the GPU is idle beside those).  GSR_NO_RIDER=1 leaves the fill to the
+# backward, for measurements of the difference.
+_RIDER = os.environ.get("GSR_NO_RIDER", "0") in ("", "0")
 # The forward is ONE call into the library (gsr_forward) unless GSR_STAGED=1 or a stage timer is installed;
 # then it is the sequence of stage calls, with the same results bit for bit.
 SINGLE_CALL = os.environ.get("GSR_STAGED", "0") in ("", "0")
@@ -63,7 +67,8 @@ class _ForwardArgs(C.Structure):
                 ("workspace", C.c_void_p), ("workspace_bytes", C.c_size_t),
                 ("h_totals", C.c_void_p), ("event", C.c_void_p), ("status", C.c_void_p),
                 ("after_preprocess", C.c_void_p), ("before_blend", C.c_void_p), ("hook_ctx", C.c_void_p),
-                ("blend_start_event", C.c_void_p), ("blend_stop_event", C.c_void_p)]
+                ("blend_start_event", C.c_void_p), ("blend_stop_event", C.c_void_p),
+                ("zero_fill", C.c_void_p), ("zero_fill_bytes", C.c_size_t)]
 
 
 class _ForwardOut(C.Structure):
@@ -370,6 +375,23 @@ def _read_back_event(dev: torch.device):
     return d["event"]
 
 
+def _thread_callbacks():
+    """The resize callback and the two hooks gsr_forward is given, one set per host thread for the life of
+    the thread.  They forward to whatever the current call has put into their slots.  A ctypes callback
+    object made per call would sit in a reference cycle, and the tensors its function holds (the tile lists:
+    a hundred megabytes a call) would stay allocated until Python's cyclic collector happened to run."""
+    cbs = getattr(_local, "callbacks", None)
+    if cbs is None:
+        slot = {"resize": None, "after_preprocess": None, "before_blend": None}
+        cbs = _local.callbacks = {
+            "slot": slot,
+            "resize": _RESIZE_FN(lambda _ctx, bytes_: slot["resize"](bytes_)),
+            "after_preprocess": _HOOK_FN(lambda _ctx: slot["after_preprocess"]()),
+            "before_blend": _HOOK_FN(lambda _ctx: slot["before_blend"]()),
+        }
+    return cbs
+
+
 def _forward_single_call(s, st, dev, means3D, opacities, shs, colors_precomp, scales, rotations, cov3D_precomp,
                          keep_tile_ids, raw, prepare_backward, ref_lists) -> None:
     """gsr_forward: fills ``st`` like the staged path does.  Everything but the user-visible outputs lives in
@@ -383,7 +405,7 @@ def _forward_single_call(s, st, dev, means3D, opacities, shs, colors_precomp, sc
     ws = torch.empty((nbytes,), **u8)
     keep = {}
 
-    def resize(_ctx, bytes_):
+    def resize(bytes_):
         keep["lists"] = torch.empty((bytes_,), **u8)
         return keep["lists"].data_ptr()
 
@@ -396,7 +418,7 @@ def _forward_single_call(s, st, dev, means3D, opacities, shs, colors_precomp, sc
         st.dsplat = torch.empty((P, GRAD_WORDS), dtype=torch.float32, device=dev)
         cleared = torch.cuda.Event()
 
-        def start_fill(_ctx):
+        def start_fill():
             handed_out = torch.cuda.Event()
             handed_out.record(main)
             side.wait_event(handed_out)
@@ -404,11 +426,15 @@ def _forward_single_call(s, st, dev, means3D, opacities, shs, colors_precomp, sc
                 st.dsplat.zero_()
                 cleared.record(side)
 
-        hooks = (_HOOK_FN(start_fill), _HOOK_FN(lambda _ctx: main.wait_event(cleared)))
+        hooks = (start_fill, lambda: main.wait_event(cleared))
 
     a = _ForwardArgs()
     a.P, a.D, a.W, a.H = P, st.D, W, H
     p = lambda t: None if t is None else t.data_ptr()
+    if prepare_backward and hooks is None and P > 0:
+        # the accumulator of the blend backward is cleared by the library beside its one-block scan kernels
+        st.dsplat = torch.empty((P, GRAD_WORDS), dtype=torch.float32, device=dev)
+        a.zero_fill, a.zero_fill_bytes = st.dsplat.data_ptr(), P * GRAD_WORDS * 4
     if raw is not None:
         r = {k: _f32(v, k) for k, v in raw.items()}
         n_rest = 0 if r["features_rest"] is None else r["features_rest"].shape[1]
@@ -430,13 +456,20 @@ def _forward_single_call(s, st, dev, means3D, opacities, shs, colors_precomp, sc
     a.workspace, a.workspace_bytes = ws.data_ptr(), nbytes
     status = _status_word(dev)
     a.h_totals, a.event, a.status = _pinned_totals(dev).data_ptr(), _read_back_event(dev), status.data_ptr()
+    cbs = _thread_callbacks()
+    slot = cbs["slot"]
+    slot["resize"] = resize
     if hooks is not None:
-        a.after_preprocess, a.before_blend = C.cast(hooks[0], C.c_void_p), C.cast(hooks[1], C.c_void_p)
+        slot["after_preprocess"], slot["before_blend"] = hooks
+        a.after_preprocess = C.cast(cbs["after_preprocess"], C.c_void_p)
+        a.before_blend = C.cast(cbs["before_blend"], C.c_void_p)
     if _timer is not None and "blend_fwd" in _timer.exact:
         a.blend_start_event, a.blend_stop_event = _timer.kernel_pair("blend_fwd")
     out = _ForwardOut()
-    cb = _RESIZE_FN(resize)
-    rc = _lib.gsr_forward(C.byref(a), cb, None, C.byref(out), _stream())
+    try:
+        rc = _lib.gsr_forward(C.byref(a), cbs["resize"], None, C.byref(out), _stream())
+    finally:
+        slot["resize"] = slot["after_preprocess"] = slot["before_blend"] = None
     del held
     if rc == GSR_E_EARLIER:
         status.zero_()
@@ -671,6 +704,16 @@ def rasterize_backward_raw(s: GaussianRasterizationSettings, st: ForwardState, g
     return g
 
 
+def _detach_image(ctx, st: ForwardState) -> torch.Tensor:
+    """Takes the image out of the forward state that the autograd node keeps.  The returned tensor gets that
+    node as its grad_fn; left on the state it would close a reference cycle (node -> state -> image -> node),
+    and every step's lists and records (hundreds of megabytes) would live until Python's cyclic collector
+    runs, which then stalls the training loop for tens of milliseconds."""
+    color, st.color = st.color, None
+    ctx.image_shape = tuple(color.shape)
+    return color
+
+
 class _RasterizeGaussiansRaw(torch.autograd.Function):
     """Same operator on the model's raw parameters: exp / sigmoid / normalize / dc|rest
     concatenation and their backward run inside the per-Gaussian kernels."""
@@ -688,13 +731,13 @@ class _RasterizeGaussiansRaw(torch.autograd.Function):
         ctx.save_for_backward(xyz, features_dc, features_rest, opacity_raw, scaling_raw, rotation_raw)
         ctx.mark_non_differentiable(st.radii, st.visible)
         ctx.set_materialize_grads(False)        # no zero tensors for the integer outputs' "gradients"
-        return st.color, st.radii, st.visible
+        return _detach_image(ctx, st), st.radii, st.visible
 
     @staticmethod
     def backward(ctx, grad_out_color, _grad_radii, _grad_visible):
         xyz, features_dc, features_rest, opacity_raw, scaling_raw, rotation_raw = ctx.saved_tensors
         if grad_out_color is None:
-            grad_out_color = torch.zeros_like(ctx.state.color)
+            grad_out_color = torch.zeros(ctx.image_shape, dtype=torch.float32, device=xyz.device)
         raw = dict(features_dc=features_dc, features_rest=_empty_to_none(features_rest), scaling=scaling_raw,
                    rotation=rotation_raw, opacity=opacity_raw)
         g = rasterize_backward_raw(ctx.raster_settings, ctx.state, grad_out_color, xyz, raw)
@@ -740,14 +783,14 @@ class _RasterizeGaussians(torch.autograd.Function):
         ctx.save_for_backward(means3D, sh, scales, rotations, cov3Ds_precomp)
         ctx.mark_non_differentiable(st.radii)
         ctx.set_materialize_grads(False)        # no zero tensor for the radii's "gradient"
-        return st.color, st.radii
+        return _detach_image(ctx, st), st.radii
 
     @staticmethod
     def backward(ctx, grad_out_color, _grad_radii):
         s, st = ctx.raster_settings, ctx.state
-        if grad_out_color is None:
-            grad_out_color = torch.zeros_like(st.color)
         means3D, sh, scales, rotations, cov3Ds_precomp = ctx.saved_tensors
+        if grad_out_color is None:
+            grad_out_color = torch.zeros(ctx.image_shape, dtype=torch.float32, device=means3D.device)
         kw = dict(shs=_empty_to_none(sh), scales=_empty_to_none(scales), rotations=_empty_to_none(rotations),
                   cov3D_precomp=_empty_to_none(cov3Ds_precomp))
         if s.debug:

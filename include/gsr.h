@@ -46,7 +46,7 @@
 extern "C" {
 #endif
 
-#define GSR_VERSION 2
+#define GSR_VERSION 3
 
 #define GSR_OK 0
 #define GSR_E_INVALID (-1)   /* bad argument (null pointer, negative size, unsupported M/D) */
@@ -265,6 +265,12 @@ int gsr_blend_fwd(int W, int H, const uint32_t* ranges, const uint32_t* point_li
  * right after stage 1 has been enqueued, and after the list builder has been
  * enqueued and before the blend is: e.g. to start work on another stream beside the
  * depth sort and to make `stream` wait for it before the blend.
+ * zero_fill, zero_fill_bytes (optional; 16-byte aligned, a multiple of 16 bytes):
+ * device memory of the caller's that is zero when the call's work on `stream`
+ * is done, e.g. the (P,16) accumulator of gsr_blend_bwd.  It is cleared by
+ * workgroups that run beside the list builder's one-block prefix-sum kernels,
+ * which otherwise leave the rest of the GPU idle: the fill costs no time of
+ * its own.
  * If totals[4] shows that an earlier call on the same status word built no
  * lists, the call stops before its own lists with GSR_E_EARLIER
  * (out->carried_status holds the bits; clearing the word is the caller's). */
@@ -281,6 +287,7 @@ typedef struct GsrForwardArgs {
   uint32_t* h_totals; void* event; uint32_t* status;
   void (*after_preprocess)(void* ctx); void (*before_blend)(void* ctx); void* hook_ctx;
   void* blend_start_event; void* blend_stop_event;   /* optional, as for gsr_blend_fwd_timed */
+  void* zero_fill; size_t zero_fill_bytes;           /* optional rider, see above */
 } GsrForwardArgs;
 typedef struct GsrForwardOut {
   uint32_t N, V, E1, E2, carried_status;

@@ -236,3 +236,24 @@ def test_single_call_forward_equals_the_stage_calls(raw):
                                single_call=True)
     torch.cuda.synchronize()
     assert st.num_rendered == 0 and torch.equal(st.color, bg.cuda()[:, None, None].expand_as(st.color))
+
+
+def test_the_forward_clears_the_backward_accumulator_beside_its_scans():
+    """prepare_backward through the single call: the (P,16) accumulator of the blend backward is handed to
+    gsr_forward as its zero-fill rider.  Whatever the block held before (the allocator's cache is poisoned
+    first), it is all zeros when the forward's work is done; also when no list is built (everything culled)."""
+    import diff_gaussian_rasterization as dgr
+    cloud, cam, bg, _ = make_scene(30_001, 500, 300, sh_degree=0, seed=21, coeffs=1)
+    s = _gpu_settings(cam, bg, 0, 1.0)
+    c = cloud.to("cuda")
+    behind = c.xyz.clone()
+    behind[:, 2] += 100.0
+    for xyz, rendered in ((c.xyz, True), (behind, False)):
+        poison = torch.full((c.xyz.shape[0], 16), float("nan"), device="cuda")
+        del poison                                     # back to the caching allocator, still NaN
+        st = dgr.rasterize_forward(s, xyz, c.opacity, shs=c.features, scales=c.scaling, rotations=c.rotation,
+                                   single_call=True, prepare_backward=True)
+        torch.cuda.synchronize()
+        assert (st.num_rendered > 0) == rendered
+        assert st.dsplat is not None and st.dsplat.shape == (c.xyz.shape[0], 16)
+        assert int(st.dsplat.view(torch.int32).abs().max()) == 0

@@ -109,3 +109,43 @@ def test_training_through_densification_and_opacity_reset():
     assert opt.step_count == 180 and model.denom.shape[0] == model._xyz.shape[0]
     assert sum(losses[120:128]) / 8 < 0.95 * sum(losses[:8]) / 8         # it has learnt something by the second densification
     assert all(l == l and l < 1.0 for l in losses)
+
+
+@pytest.mark.parametrize("fused", [True, False])
+def test_a_train_step_leaves_nothing_for_the_cyclic_collector(fused):
+    """Reference counting alone must free a step's tensors (tile lists, records, accumulators: hundreds of
+    megabytes at 1M Gaussians).  With the cyclic collector switched off, the allocated device memory after
+    each of several steps is the same, for the raw-parameter path and for the reference's operator API."""
+    import gc
+    from gsplat_host.cameras import orbit_camera
+    from gsplat_host.loss import photometric_loss
+    from gsplat_host.model import GaussianParams
+    from gsplat_host.render import PipelineParams, render
+    from gsplat_host.synthetic import make_cloud
+    dev = torch.device("cuda", 0)
+    model = GaussianParams(make_cloud(20_000, sh_degree=3, seed=31), max_sh_degree=3, device=dev)
+    cam = orbit_camera(320, 200, device=dev)
+    bg = torch.zeros(3, device=dev)
+    gt = torch.rand((3, 200, 320), device=dev)
+    pipe = PipelineParams(fused_activations=fused)
+
+    def step():
+        for p in model.parameters():
+            p.grad = None
+        out = render(cam, model, pipe, bg)
+        photometric_loss(out["render"], gt).backward()
+
+    step()
+    step()
+    torch.cuda.synchronize()
+    gc.collect()
+    gc.disable()
+    try:
+        held = []
+        for _ in range(4):
+            step()
+            torch.cuda.synchronize()
+            held.append(torch.cuda.memory_allocated())
+    finally:
+        gc.enable()
+    assert len(set(held)) == 1, held
