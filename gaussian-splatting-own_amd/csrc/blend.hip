@@ -192,9 +192,10 @@ __global__ void __launch_bounds__(256) blend_fwd_kernel(int W, int H, const uint
           // alpha = min(.99, oG) is kept iff the exponent is <= 0 and alpha >= 1/255, i.e. oG >= 1/255
           const float oG = co.y * __builtin_amdgcn_exp2f(p);
           const bool keep = (p <= 0.0f) & (oG >= accept);
-          if (__ballot(keep) == 0ull) continue;               // no pixel of the quadrant takes this splat
           // Pixels that do not take the splat keep computing with whatever their alpha is; every
-          // state update below selects on the decision masks (scalar registers), so none of it lands.
+          // state update below selects on the decision masks, so none of it lands.  (No early "does any
+          // pixel of the quadrant take it" test: the vote and its branch cost every splat more than the
+          // few instructions below cost the rare splat that none takes.)
           const float alpha = __builtin_amdgcn_fmed3f(oG, 0.0f, GSR_ALPHA_MAX);   // min(.99, oG) for oG >= 0
           const float test_T = T * (1.0f - alpha);
           const bool stop = keep & (test_T < GSR_T_STOP);      // this splat would take the pixel below 1e-4: it ends here
