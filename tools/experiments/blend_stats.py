@@ -20,8 +20,9 @@ from gsplat_host.synthetic import make_cloud  # noqa: E402
 
 for wl in sys.argv[1:] or ["c3"]:
     dev = torch.device("cuda", 0)
-    P, W, H, deg, skew = bench.WORKLOADS[wl]
-    model = GaussianParams(make_cloud(P, sh_degree=deg, seed=0, skew_fraction=skew), max_sh_degree=3, device=dev)
+    P, W, H, deg, skew, opacity = bench.WORKLOADS[wl]
+    model = GaussianParams(make_cloud(P, sh_degree=deg, seed=0, skew_fraction=skew, opacity_const=opacity),
+                           max_sh_degree=3, device=dev)
     cam = orbit_camera(W, H, angle_deg=0.0, device=dev)
     bg = torch.zeros(3, device=dev)
     gt = torch.rand(3, H, W, generator=torch.Generator().manual_seed(1)).to(dev)

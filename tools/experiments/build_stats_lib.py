@@ -22,14 +22,19 @@ extern "C" int gsr_blend_stats(unsigned long long* out, int reset) {
 namespace {
 
 constexpr int kBatch = 256;''')
-    s = once(s, "          if (__ballot(keep) == 0ull) continue;", '''          { const unsigned long long bk = __ballot(keep);
+    s = once(s, "          const bool keep = (p <= 0.0f) & (oG >= accept);\n", '''          const bool keep = (p <= 0.0f) & (oG >= accept);
+          { const unsigned long long bk = __ballot(keep);
             if (lane == 0) { atomicAdd(&g_stats[0], 1ull); if (bk) { atomicAdd(&g_stats[1], 1ull); atomicAdd(&g_stats[2], (unsigned long long)__popcll(bk)); } } }
-          if (__ballot(keep) == 0ull) continue;''')
+''')
     s = once(s, "        if (__ballot(hit) == 0ull) continue;", '''        { const unsigned long long bk = __ballot(hit);
           if (lane == 0) { atomicAdd(&g_stats[4], 1ull); if (bk) { atomicAdd(&g_stats[5], 1ull); atomicAdd(&g_stats[6], (unsigned long long)__popcll(bk)); } } }
         if (__ballot(hit) == 0ull) continue;''')
-    s = once(s, "      s_id[threadIdx.x] = g;", "      s_id[threadIdx.x] = g;\n      atomicAdd(&g_stats[7], 1ull);")
-    s = once(s, "      s_blue[threadIdx.x] = sp.blue;\n    }\n", "      s_blue[threadIdx.x] = sp.blue;\n      atomicAdd(&g_stats[3], 1ull);\n    }\n")
+    staged = "      stage_record(&s_splat[threadIdx.x], r0, r1, r2, g);\n"
+    assert s.count(staged) == 2                      # forward first, backward second
+    first = s.index(staged)
+    second = s.index(staged, first + 1)
+    s = s[:second] + staged + "      atomicAdd(&g_stats[7], 1ull);\n" + s[second + len(staged):]
+    s = s[:first] + staged + "      atomicAdd(&g_stats[3], 1ull);\n" + s[first + len(staged):]
     return s
 
 
