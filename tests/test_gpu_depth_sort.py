@@ -45,7 +45,7 @@ def _depth_keys(rng, P, culled_fraction, lo=0.2, hi=30.0):
     return keys
 
 
-@pytest.mark.parametrize("P", [1, 63, 64, 65, 4095, 4096, 4097, 65536, 65537, 300_001])
+@pytest.mark.parametrize("P", [1, 63, 64, 65, 2047, 2048, 2049, 4095, 4096, 4097, 65536, 65537, 199_999, 200_000, 300_001])
 def test_sizes_around_the_block_boundaries(P):
     rng = np.random.default_rng(P)
     _check(_depth_keys(rng, P, 0.2), rng.integers(0, 2**63, P, dtype=np.uint64))
