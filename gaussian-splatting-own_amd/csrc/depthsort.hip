@@ -56,8 +56,29 @@ constexpr uint32_t kSpinLimit = 1u << 22;  // look-back steps before giving up (
 std::atomic<uint32_t> g_spin_limit{kSpinLimit};
 
 // control words behind the 4 x 256 histogram bins
-enum { kCtlValid = 0, kCtlTicket = 1, kCtlError = 5, kCtlWords = 16 };
-constexpr int kHistWords = 4 * 256;
+enum { kCtlTicket = 0, kCtlError = 4, kCtlValid = 8, kCtlWords = 16 };   // 4 tickets, the error word, 8 partial key counts
+// The digit histograms of the four passes, kHistCopies times over: workgroup b of the histogram kernel adds
+// its counts to copy b % kHistCopies, the readers add the copies up.  Atomics of many workgroups on ONE word
+// retire one after the other (tens of nanoseconds each, device scope on a part with eight L2s); with 245
+// workgroups flushing into one copy that was a third of the kernel's time.
+constexpr int kHistCopies = 8;
+static_assert(kCtlValid + kHistCopies <= kCtlWords, "one partial count of valid keys per histogram copy");
+constexpr int kHistCopyWords = 4 * 256;
+constexpr int kHistWords = kHistCopies * kHistCopyWords;
+
+__device__ __forceinline__ uint32_t hist_bin(const uint32_t* __restrict__ hist, int pass, int digit) {
+  uint32_t n = 0;
+#pragma unroll
+  for (int c = 0; c < kHistCopies; c++) n += hist[c * kHistCopyWords + 256 * pass + digit];
+  return n;
+}
+
+__device__ __forceinline__ uint32_t valid_keys(const uint32_t* __restrict__ ctl) {
+  uint32_t n = 0;
+#pragma unroll
+  for (int c = 0; c < kHistCopies; c++) n += ctl[kCtlValid + c];
+  return n;
+}
 
 __device__ __forceinline__ uint32_t wave_incl_scan(uint32_t v) {
   const int lane = threadIdx.x & 63;
@@ -87,7 +108,7 @@ __global__ void __launch_bounds__(256) sort_clear_kernel(uint32_t* __restrict__ 
 __global__ void __launch_bounds__(kThreads) sort_histogram_kernel(const uint32_t* __restrict__ keys, uint32_t P,
                                                                   uint32_t* __restrict__ hist,
                                                                   uint32_t* __restrict__ ctl) {
-  __shared__ uint32_t s_h[kHistWords];
+  __shared__ uint32_t s_h[kHistCopyWords];
   __shared__ uint32_t s_valid;
   s_h[threadIdx.x] = 0u;
   if (threadIdx.x == 0) s_valid = 0u;
@@ -131,8 +152,8 @@ __global__ void __launch_bounds__(kThreads) sort_histogram_kernel(const uint32_t
   if ((threadIdx.x & 63) == 0 && valid) atomicAdd(&s_valid, valid);
   __syncthreads();
   const uint32_t c = s_h[threadIdx.x];
-  if (c) atomicAdd(&hist[threadIdx.x], c);
-  if (threadIdx.x == 0 && s_valid) atomicAdd(&ctl[kCtlValid], s_valid);   // one word for everybody: once per workgroup
+  if (c) atomicAdd(&hist[(blockIdx.x % kHistCopies) * kHistCopyWords + threadIdx.x], c);
+  if (threadIdx.x == 0 && s_valid) atomicAdd(&ctl[kCtlValid + (blockIdx.x % kHistCopies)], s_valid);   // once per workgroup
 }
 
 struct PassArgs {
@@ -141,12 +162,13 @@ struct PassArgs {
   uint32_t* keys_out;     // unused by the last pass
   u64* vals_out;
   u64* final_out;         // passes 2 and 3: the sort's result (sorted_vals)
-  const uint32_t* hist;   // this pass's 256 bins
+  const uint32_t* hist;   // all copies of the four digit histograms
   uint32_t* ctl;
   uint32_t* states;       // [workgroup][256] look-back words of this pass
   uint32_t* group_states; // [group][256]
   uint32_t P;
   uint32_t spin_limit;    // look-back steps before a workgroup gives up and flags the sort as failed
+  uint32_t static_order;  // workgroup b takes chunk b (the whole grid is resident at once) instead of drawing a ticket
 };
 
 // Sum of the counts published at states[q][t] for q = p, p-1, ..., stop, newest first, waiting
@@ -210,30 +232,33 @@ __global__ void __launch_bounds__(kThreads) sort_pass_kernel(PassArgs a) {
 
   // One bin of the top byte's histogram holds every key: the last pass would move nothing.  Pass 2 then
   // writes the result itself and pass 3 has nothing to do.  The test reads this pass's view of the
-  // top-byte histogram (hist + 256 for pass 2, hist for pass 3) against the number of valid keys;
+  // top-byte histogram against the number of valid keys;
   // every workgroup of both kernels comes to the same answer.
   bool top_byte_is_constant = false;
   if (PASS >= 2) {
-    const uint32_t* top = PASS == 2 ? a.hist + 256 : a.hist;
-    const uint32_t all = a.ctl[kCtlValid];
-    top_byte_is_constant = __syncthreads_or(threadIdx.x < 256 && all != 0u && top[threadIdx.x & 255] == all) != 0;
+    const uint32_t all = valid_keys(a.ctl);
+    top_byte_is_constant = __syncthreads_or(threadIdx.x < 256 && all != 0u && hist_bin(a.hist, 3, threadIdx.x & 255) == all) != 0;
     if (PASS == 3 && top_byte_is_constant) return;
   }
   const bool writes_result = PASS == 3 || (PASS == 2 && top_byte_is_constant);
   u64* const vals_dst = writes_result ? a.final_out : a.vals_out;
 
-  if (tid == 0) s_misc[0] = atomicAdd(&a.ctl[kCtlTicket + PASS], 1u);
+  // Which chunk: a look-back waits for the workgroups of all earlier chunks, so those must be running or done.
+  // A ticket drawn at start-up guarantees that whatever order the hardware starts workgroups in; when the
+  // whole grid fits on the GPU at once (the host checks) the workgroup's own index does, and saves 245
+  // atomics on one word that retire one after the other (1.5 us of every pass at 1M keys).
+  if (tid == 0) s_misc[0] = a.static_order ? blockIdx.x : atomicAdd(&a.ctl[kCtlTicket + PASS], 1u);
   if (tid < 256) s_total[tid] = 0u;
 #pragma unroll
   for (int k = 0; k < kWaves * 256 / kThreads; k++) (&s_count[0][0])[k * kThreads + tid] = 0u;
   __syncthreads();
   const uint32_t wg = s_misc[0];
   STAMP(0);
-  const uint32_t n = PASS == 0 ? a.P : a.ctl[kCtlValid];
+  const uint32_t n = PASS == 0 ? a.P : valid_keys(a.ctl);
   const uint32_t base = wg * (uint32_t)kItems;
   if (base >= n) return;                       // the whole workgroup: nothing left for it
 
-  const uint32_t bin = tid < 256 ? a.hist[tid] : 0u;
+  const uint32_t bin = tid < 256 ? hist_bin(a.hist, PASS, tid) : 0u;
 
   uint32_t key[kItemsPerThread], digit[kItemsPerThread], rank[kItemsPerThread];
   u64 val[kItemsPerThread];
@@ -391,6 +416,42 @@ Layout layout(uint32_t P) {
 
 }  // namespace
 
+namespace {
+
+// How many workgroups of the pass kernels (the most demanding of the four) the current device holds at once;
+// 0 if that cannot be found out.  Asked once per device and keys-per-thread variant.
+template <int I>
+uint32_t resident_of() {
+  int dev = 0, cus = 0, per_cu = 1 << 30;
+  if (hipGetDevice(&dev) != hipSuccess) return 0;
+  if (hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess) return 0;
+  const void* kernels[4] = {(const void*)sort_pass_kernel<0, I>, (const void*)sort_pass_kernel<1, I>,
+                            (const void*)sort_pass_kernel<2, I>, (const void*)sort_pass_kernel<3, I>};
+  for (const void* k : kernels) {
+    int n = 0;
+    if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&n, k, kThreads, 0) != hipSuccess) { (void)hipGetLastError(); return 0; }
+    per_cu = n < per_cu ? n : per_cu;
+  }
+  return (uint32_t)(cus > 0 && per_cu > 0 ? cus * per_cu : 0);
+}
+
+uint32_t resident_workgroups(int items) {
+  static std::mutex m;
+  static uint32_t cache[64][3];                 // [device][variant], 0 = not asked yet
+  static bool asked[64][3];
+  int dev = 0;
+  if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 64) return 0;
+  const int v = items == kManyItems ? 2 : items == kFewItems ? 1 : 0;
+  std::lock_guard<std::mutex> lock(m);
+  if (!asked[dev][v]) {
+    cache[dev][v] = v == 2 ? resident_of<kManyItems>() : v == 1 ? resident_of<kFewItems>() : resident_of<kTinyItems>();
+    asked[dev][v] = true;
+  }
+  return cache[dev][v];
+}
+
+}  // namespace
+
 namespace gsr {
 
 size_t depth_sort_bytes(int P) { return P > 0 ? layout((uint32_t)P).total : 256; }
@@ -421,10 +482,11 @@ int depth_sort(int P, const uint32_t* keys, const uint64_t* vals, uint64_t* sort
   hipLaunchKernelGGL(sort_histogram_kernel, dim3(hist_blocks), dim3(kThreads), 0, st, keys, (uint32_t)P, hist, ctl);
   const dim3 grid(L.workgroups), block(kThreads);
   const uint32_t spin_limit = g_spin_limit.load(std::memory_order_relaxed);
+  const uint32_t static_order = L.workgroups <= resident_workgroups(items_per_thread((uint32_t)P)) ? 1u : 0u;
   const size_t per_pass = L.state_words + L.group_words;
   auto args = [&](int pass, const uint32_t* kin, const u64* vin, uint32_t* kout, u64* vout) {
     uint32_t* s = states + pass * per_pass;
-    return PassArgs{kin, vin, kout, vout, (u64*)sorted_vals, hist + 256 * pass, ctl, s, s + L.state_words, (uint32_t)P, spin_limit};
+    return PassArgs{kin, vin, kout, vout, (u64*)sorted_vals, hist, ctl, s, s + L.state_words, (uint32_t)P, spin_limit, static_order};
   };
   auto passes = [&](auto items) {
     constexpr int I = decltype(items)::value;
@@ -471,7 +533,7 @@ namespace {
 
 constexpr int kStaticMaxKeys = 1 << 20;
 // what layout(kStaticMaxKeys) asks for: look-back words and histograms (1.1 MB) + two key and two value buffers
-constexpr size_t kStaticBytes = 26284288;
+constexpr size_t kStaticBytes = 26312960;
 
 // Every GPU the library runs on holds its own copy of this array, at its own address, until the process ends.
 static __device__ __align__(256) unsigned char scratch[kStaticBytes];

@@ -185,7 +185,7 @@ void gsr_debug_sort_spin_limit(uint32_t limit);
 
 /* gsr_bin_sort_static: gsr_bin_sort for callers that cannot allocate device memory or have
  * none to hand in (code under HIP graph capture, tight serving loops, harnesses that forbid
- * hipMalloc).  It has no counterpart in the reference.  The sort's scratch is a 26,284,288-byte
+ * hipMalloc).  It has no counterpart in the reference.  The sort's scratch is a 26,312,960-byte
  * device array inside the library (every GPU the library runs on holds its own copy until the
  * process ends), so P is limited to GSR_BIN_SORT_STATIC_MAX = 2^20 keys: more is refused with
  * GSR_E_TOO_LARGE.  The call allocates nothing (no hipMalloc / hipFree, no allocating library
