@@ -132,7 +132,7 @@ void try_handwritten(uint32_t P, const uint32_t* keys, const u64* vals, u64* vo,
     }
   }
 #endif
-  printf("hand-written (visible %u, counted %u, error word %u) %8.1f us  %s\n", V, ctl[0], ctl[5], ms * 1e3f,
+  printf("hand-written (visible %u, counted %u, error word %u) %8.1f us  %s\n", V, ctl[8] + ctl[9] + ctl[10] + ctl[11] + ctl[12] + ctl[13] + ctl[14] + ctl[15], ctl[4], ms * 1e3f,
          ok ? "exact" : "MISMATCH");
   fflush(stdout);
   CK(hipFree(tmp));
