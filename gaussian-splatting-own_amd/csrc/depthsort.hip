@@ -171,20 +171,26 @@ struct PassArgs {
   uint32_t static_order;  // workgroup b takes chunk b (the whole grid is resident at once) instead of drawing a ticket
 };
 
-// Sum of the counts published at states[q][t] for q = p, p-1, ..., stop, newest first, waiting
-// for words that are still empty and ending early at a word flagged complete (which already
-// holds everything before it).
-__device__ __forceinline__ uint32_t look_back(const uint32_t* states, int p, int stop, int t, uint32_t spin_limit,
-                                              uint32_t* error_word, uint32_t error_bit) {
+// Look-back over the counts published at states[q][t] for q = p, p-1, ..., stop, newest first: a window of
+// kWindow words is loaded at once (device-coherent loads: a round trip past the L2s, a microsecond each
+// round), then eaten from the newest on, up to the first word that is still empty (wait for it: load again
+// from there) or flagged complete (it already holds everything before it: done).
+struct LookBack {
+  const uint32_t* states;
+  int p, stop, t;
   uint32_t sum = 0, spins = 0;
-  while (p >= stop) {
-    uint32_t st[kWindow];
+  bool done;
+  uint32_t st[kWindow];
+  __device__ __forceinline__ LookBack(const uint32_t* s, int p_, int stop_, int t_) : states(s), p(p_), stop(stop_), t(t_), done(p_ < stop_) {}
+  __device__ __forceinline__ void load() {
 #pragma unroll
     for (int j = 0; j < kWindow; j++)
-      st[j] = (p - j >= stop) ? __hip_atomic_load(states + (size_t)(p - j) * 256 + t, __ATOMIC_RELAXED,
-                                                  __HIP_MEMORY_SCOPE_AGENT)
-                              : kComplete;
-    bool done = false;
+      st[j] = (!done && p - j >= stop) ? __hip_atomic_load(states + (size_t)(p - j) * 256 + t, __ATOMIC_RELAXED,
+                                                            __HIP_MEMORY_SCOPE_AGENT)
+                                       : kComplete;
+  }
+  __device__ __forceinline__ void eat() {
+    if (done) return;
     int used = 0;
 #pragma unroll
     for (int j = 0; j < kWindow; j++) {
@@ -194,11 +200,26 @@ __device__ __forceinline__ uint32_t look_back(const uint32_t* states, int p, int
         done = (st[j] & kFlags) == kComplete;
       }
     }
-    if (done) break;
     p -= used;
-    if (++spins > spin_limit) { atomicOr(error_word, error_bit); break; }
+    done = done || p < stop;
   }
-  return sum;
+  // the rest of the way, one window after the other
+  __device__ __forceinline__ uint32_t finish(uint32_t spin_limit, uint32_t* error_word, uint32_t error_bit) {
+    while (!done) {
+      if (++spins > spin_limit) { atomicOr(error_word, error_bit); break; }
+      load();
+      eat();
+    }
+    return sum;
+  }
+};
+
+__device__ __forceinline__ uint32_t look_back(const uint32_t* states, int p, int stop, int t, uint32_t spin_limit,
+                                              uint32_t* error_word, uint32_t error_bit) {
+  LookBack lb(states, p, stop, t);
+  lb.load();
+  lb.eat();
+  return lb.finish(spin_limit, error_word, error_bit);
 }
 
 // One radix pass.  PASS 0 reads all P keys and drops the culled ones; later passes read the
@@ -350,10 +371,16 @@ __global__ void __launch_bounds__(kThreads) sort_pass_kernel(PassArgs a) {
     for (int w = 0; w < wave; w++) { local0 += s_misc[4 + w]; bin0 += s_misc[8 + w]; }
     if (tid == 255) s_misc[1] = local0 + total;                     // valid items in this workgroup
 
-    // look-back: how many items with this digit sit in earlier workgroups
-    if (!closes_group)
-      in_group = look_back(a.states, (int)wg - 1, group * kGroup, tid, a.spin_limit, &a.ctl[kCtlError], 1u << PASS);
-    const uint32_t groups_before = look_back(a.group_states, group - 1, 0, tid, a.spin_limit, &a.ctl[kCtlError], 16u << PASS);
+    // look-back: how many items with this digit sit in earlier workgroups of this group and in earlier groups;
+    // the first windows of both are in flight together
+    LookBack mine(a.states, closes_group ? -1 : (int)wg - 1, closes_group ? 0 : group * kGroup, tid);
+    LookBack theirs(a.group_states, group - 1, 0, tid);
+    mine.load();
+    theirs.load();
+    mine.eat();
+    theirs.eat();
+    if (!closes_group) in_group = mine.finish(a.spin_limit, &a.ctl[kCtlError], 1u << PASS);
+    const uint32_t groups_before = theirs.finish(a.spin_limit, &a.ctl[kCtlError], 16u << PASS);
     if (closes_group)
       __hip_atomic_store(group_word, kComplete | (groups_before + in_group + total), __ATOMIC_RELAXED,
                          __HIP_MEMORY_SCOPE_AGENT);
