@@ -522,22 +522,72 @@ __device__ __forceinline__ uint32_t owner_of(const uint32_t* first, uint32_t n, 
 
 // Cuts the lists (list_start, list_len)[0..n) into pieces of at most piece_len entries:
 // piece_first (n + 1 words, holds the piece counts on entry) and the descriptors.
-constexpr uint32_t kFirstLds = 4096;    // piece_first is searched from LDS when it has at most this many words
+// Every step that reads from global memory what an earlier step of the same block wrote is a round trip of
+// a microsecond in a kernel that has nothing to hide it behind, so when the lists fit (n + 1 <= kFirstLds:
+// any image up to 4096 cells) they never leave LDS: LdsLists holds start, length and piece count of every
+// list, the scan of the piece counts runs there, and the descriptors are built from there; only piece_first
+// and the descriptors, which the next kernels read, are written out.
+constexpr uint32_t kFirstLds = 4096;
+
+struct LdsLists {
+  uint32_t* start;   // [kFirstLds]
+  uint32_t* len;     // [kFirstLds]
+  uint32_t* first;   // [kFirstLds]: piece counts in, first piece of every list out (n + 1 words)
+};
+
+// Exclusive scan of a[0..n) in LDS, n <= 4 * kScanBlock; returns the total.  Contains barriers.
+__device__ uint32_t block_scan_lds(uint32_t* a, uint32_t n, uint32_t* s_wave) {
+  static_assert(kFirstLds <= 4 * kScanBlock, "four words per thread");
+  const uint32_t lane = threadIdx.x & 63u, w = threadIdx.x >> 6, i0 = 4u * threadIdx.x;
+  uint32_t v[4], s = 0;
+#pragma unroll
+  for (int k = 0; k < 4; k++) { v[k] = i0 + k < n ? a[i0 + k] : 0u; s += v[k]; }
+  uint32_t inc = s;
+#pragma unroll
+  for (int o = 1; o < 64; o <<= 1) {
+    const uint32_t u = __shfl_up(inc, o);
+    if (lane >= o) inc += u;
+  }
+  __syncthreads();
+  if (lane == 63) s_wave[w] = inc;
+  __syncthreads();
+  uint32_t before = 0, tot = 0;
+#pragma unroll
+  for (int k = 0; k < kScanBlock / 64; k++) {
+    const uint32_t x = s_wave[k];
+    before += (uint32_t)k < w ? x : 0u;
+    tot += x;
+  }
+  uint32_t ex = before + inc - s;
+#pragma unroll
+  for (int k = 0; k < 4; k++) {
+    if (i0 + k < n) a[i0 + k] = ex;
+    ex += v[k];
+  }
+  __syncthreads();
+  return tot;
+}
+
+__device__ void build_pieces_lds(uint32_t n, const LdsLists& L, uint32_t piece_len, uint32_t* piece_first, uint4* desc,
+                                 uint32_t* s_wave) {
+  __syncthreads();
+  const uint32_t pieces = block_scan_lds(L.first, n + 1, s_wave);
+  for (uint32_t b = threadIdx.x; b <= n; b += kScanBlock) piece_first[b] = L.first[b];
+  for (uint32_t q = threadIdx.x; q < pieces; q += kScanBlock) {
+    const uint32_t b = owner_of(L.first, n, q);
+    const uint32_t j = q - L.first[b];
+    desc[q] = make_uint4(b, L.start[b] + j * piece_len, min(piece_len, L.len[b] - j * piece_len), j);
+  }
+}
 
 __device__ void build_pieces(uint32_t n, const uint32_t* list_start, const uint32_t* list_len, uint32_t piece_len,
-                             uint32_t* piece_first, uint4* desc, uint32_t* s_wave, uint32_t* s_first) {
+                             uint32_t* piece_first, uint4* desc, uint32_t* s_wave) {
   __syncthreads();
   const uint32_t pieces = block_scan_inplace(piece_first, n + 1, s_wave);
   __syncthreads();
-  const uint32_t* first = piece_first;
-  if (n + 1 <= kFirstLds) {
-    for (uint32_t b = threadIdx.x; b <= n; b += kScanBlock) s_first[b] = piece_first[b];
-    __syncthreads();
-    first = s_first;
-  }
   for (uint32_t q = threadIdx.x; q < pieces; q += kScanBlock) {
-    const uint32_t b = owner_of(first, n, q);
-    const uint32_t j = q - first[b];
+    const uint32_t b = owner_of(piece_first, n, q);
+    const uint32_t j = q - piece_first[b];
     const uint32_t len = list_len[b];
     desc[q] = make_uint4(b, list_start[b] + j * piece_len, min(piece_len, len - j * piece_len), j);
   }
@@ -548,7 +598,7 @@ __global__ void __launch_bounds__(kScanBlock) scan1_kernel(Grid g, Guard guard, 
                                                            uint32_t* counts, uint32_t* list_start,
                                                            uint32_t* list_len, uint32_t* piece_first, uint4* desc) {
   __shared__ uint32_t s_wave[kScanBlock / 64];
-  __shared__ uint32_t s_first[kFirstLds];
+  __shared__ uint32_t s_start[kFirstLds], s_len[kFirstLds], s_first[kFirstLds];
   const uint32_t F = (uint32_t)g.supercells(), np = (V + kPiece1 - 1) / kPiece1, slots = np * F;
   const uint32_t refused = guard.refusal();
   if (refused) {
@@ -559,15 +609,20 @@ __global__ void __launch_bounds__(kScanBlock) scan1_kernel(Grid g, Guard guard, 
   }
   const uint32_t total = block_scan_inplace(counts, slots, s_wave);
   __syncthreads();
+  const bool in_lds = F + 1 <= kFirstLds;
   for (uint32_t b = threadIdx.x; b < F; b += kScanBlock) {
     const uint32_t begin = np ? counts[b * np] : 0u;
     const uint32_t end = (np && b + 1 < F) ? counts[(b + 1) * np] : total;
-    list_start[b] = begin;
-    list_len[b] = end - begin;
-    piece_first[b] = (end - begin + kPiece2 - 1) / kPiece2;
+    const uint32_t pieces = (end - begin + kPiece2 - 1) / kPiece2;
+    if (in_lds) {
+      s_start[b] = begin; s_len[b] = end - begin; s_first[b] = pieces;
+    } else {
+      list_start[b] = begin; list_len[b] = end - begin; piece_first[b] = pieces;
+    }
   }
-  if (threadIdx.x == 0) piece_first[F] = 0u;
-  build_pieces(F, list_start, list_len, kPiece2, piece_first, desc, s_wave, s_first);
+  if (threadIdx.x == 0) { if (in_lds) s_first[F] = 0u; else piece_first[F] = 0u; }
+  if (in_lds) build_pieces_lds(F, LdsLists{s_start, s_len, s_first}, kPiece2, piece_first, desc, s_wave);
+  else build_pieces(F, list_start, list_len, kPiece2, piece_first, desc, s_wave);
 }
 
 // After the level-2 counting sweep: positions, the cell lists (row-major cell ids), the level-3 pieces.
@@ -593,11 +648,12 @@ __global__ void __launch_bounds__(kScanBlock) scan2_kernel(Grid g, const uint32_
                                                            uint32_t* piece_first, uint4* desc, RiderFill fill) {
   if (blockIdx.x > 0) { rider_fill(fill); return; }
   __shared__ uint32_t s_wave[kScanBlock / 64];
-  __shared__ uint32_t s_first[kFirstLds];
-  const uint32_t parents = (uint32_t)g.supercells();
+  __shared__ uint32_t s_start[kFirstLds], s_len[kFirstLds], s_first[kFirstLds];
+  const uint32_t parents = (uint32_t)g.supercells(), cells = (uint32_t)g.cells();
   const uint32_t slots = piece_first2[parents] * kSuper;
   const uint32_t total = block_scan_inplace(counts, slots, s_wave);
   __syncthreads();
+  const bool in_lds = cells + 1 <= kFirstLds;
   for (uint32_t q = threadIdx.x; q < parents * kSuper; q += kScanBlock) {
     const uint32_t p = q / kSuper, f = q % kSuper;
     const uint32_t y = (p / g.sx) * kSuper + f;
@@ -610,12 +666,16 @@ __global__ void __launch_bounds__(kScanBlock) scan2_kernel(Grid g, const uint32_
       end = s0 + np < slots ? counts[s0 + np] : total;
     }
     const uint32_t cell = y * g.sx + p % g.sx;
-    list_start[cell] = begin;
-    list_len[cell] = end - begin;
-    piece_first[cell] = (end - begin + kPiece3 - 1) / kPiece3;
+    const uint32_t pieces = (end - begin + kPiece3 - 1) / kPiece3;
+    if (in_lds) {
+      s_start[cell] = begin; s_len[cell] = end - begin; s_first[cell] = pieces;
+    } else {
+      list_start[cell] = begin; list_len[cell] = end - begin; piece_first[cell] = pieces;
+    }
   }
-  if (threadIdx.x == 0) piece_first[g.cells()] = 0u;
-  build_pieces((uint32_t)g.cells(), list_start, list_len, kPiece3, piece_first, desc, s_wave, s_first);
+  if (threadIdx.x == 0) { if (in_lds) s_first[cells] = 0u; else piece_first[cells] = 0u; }
+  if (in_lds) build_pieces_lds(cells, LdsLists{s_start, s_len, s_first}, kPiece3, piece_first, desc, s_wave);
+  else build_pieces(cells, list_start, list_len, kPiece3, piece_first, desc, s_wave);
 }
 
 // After the level-3 counting sweep: positions in point_list and the tile ranges,

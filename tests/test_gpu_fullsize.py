@@ -84,8 +84,8 @@ def c3(request):
     torch.cuda.empty_cache()
 
 
-def test_c3_lists_are_sorted_and_partition_the_instances(c3):
-    dgr, s, c, st = c3
+def _check_lists(st, s):
+    """The tile lists are the (tile, depth, index)-sorted instances of the Gaussians' rectangles, and the ranges cut them."""
     N = st.num_rendered
     assert N == int(st.tiles_touched.to(torch.int64).sum())
     keys = st.sort_keys()
@@ -112,6 +112,35 @@ def test_c3_lists_are_sorted_and_partition_the_instances(c3):
     per_g = torch.bincount(pl, minlength=st.P)
     assert bool((per_g == st.tiles_touched.to(torch.int64)).all())
     assert bool(((st.radii > 0) == (st.tiles_touched > 0)).all())
+
+
+def test_c3_lists_are_sorted_and_partition_the_instances(c3):
+    dgr, s, c, st = c3
+    _check_lists(st, s)
+
+
+@pytest.mark.parametrize("W,H", [(8192, 8192), (16400, 16400)])
+def test_lists_on_tile_grids_too_large_for_the_scan_kernels_lds(W, H):
+    """The list builder's prefix-sum kernels keep the lists of one level in LDS when there are at most 4095 of
+    them; beyond that (more than 4095 cells: 8192 x 8192, more than 4095 supercells: 16400 x 16400) they go
+    through global memory.  Same properties as at 1080p, and the single call equals the stage calls."""
+    import diff_gaussian_rasterization as dgr
+    cloud, cam, bg, _ = make_scene(6_000, W, H, sh_degree=0, seed=3, coeffs=1)
+    s = _gpu_settings(cam, bg, 0, 1.0)
+    c = cloud.to("cuda")
+    st = dgr.rasterize_forward(s, c.xyz, c.opacity, shs=c.features, scales=c.scaling, rotations=c.rotation,
+                               keep_tile_ids=True, reference_lists=True, single_call=True)
+    torch.cuda.synchronize()
+    print(f"{W}x{H}: visible {st.num_visible}, instances {st.num_rendered}", flush=True)
+    assert st.num_rendered > 0
+    _check_lists(st, s)
+    staged = dgr.rasterize_forward(s, c.xyz, c.opacity, shs=c.features, scales=c.scaling, rotations=c.rotation,
+                                   keep_tile_ids=True, reference_lists=True, single_call=False)
+    torch.cuda.synchronize()
+    assert torch.equal(st.point_list, staged.point_list) and torch.equal(st.ranges, staged.ranges)
+    assert torch.equal(st.color, staged.color)
+    del st, staged
+    torch.cuda.empty_cache()
 
 
 def test_c3_forward_is_deterministic_and_bounded(c3):
