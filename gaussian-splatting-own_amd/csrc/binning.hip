@@ -593,10 +593,29 @@ __device__ void build_pieces(uint32_t n, const uint32_t* list_start, const uint3
   }
 }
 
+// A one-block scan leaves the other 255 CUs idle for ten microseconds.  A caller's zero-fill can ride along:
+// workgroups 1 .. gridDim.x-1 of the launch clear `vecs` 16-byte words and leave, workgroup 0 scans.
+struct RiderFill {
+  uint4* at;
+  size_t vecs;
+};
+
+__device__ __forceinline__ void rider_fill(const RiderFill& f) {
+  const size_t stride = (size_t)(gridDim.x - 1) * kScanBlock;
+  for (size_t i = (size_t)(blockIdx.x - 1) * kScanBlock + threadIdx.x; i < f.vecs; i += stride) f.at[i] = make_uint4(0u, 0u, 0u, 0u);
+}
+
+inline unsigned rider_blocks(size_t vecs) {   // enough workgroups of 1024 threads for four stores per thread, at most 2 per CU
+  const size_t want = (vecs + 4 * kScanBlock - 1) / (4 * kScanBlock);
+  return (unsigned)(want < 512 ? want : 512);
+}
+
 // After the level-1 counting sweep: positions, the supercell lists, the level-2 pieces.
 __global__ void __launch_bounds__(kScanBlock) scan1_kernel(Grid g, Guard guard, uint32_t* status, uint32_t V,
                                                            uint32_t* counts, uint32_t* list_start,
-                                                           uint32_t* list_len, uint32_t* piece_first, uint4* desc) {
+                                                           uint32_t* list_len, uint32_t* piece_first, uint4* desc,
+                                                           RiderFill fill) {
+  if (blockIdx.x > 0) { rider_fill(fill); return; }
   __shared__ uint32_t s_wave[kScanBlock / 64];
   __shared__ uint32_t s_start[kFirstLds], s_len[kFirstLds], s_first[kFirstLds];
   const uint32_t F = (uint32_t)g.supercells(), np = (V + kPiece1 - 1) / kPiece1, slots = np * F;
@@ -626,23 +645,6 @@ __global__ void __launch_bounds__(kScanBlock) scan1_kernel(Grid g, Guard guard, 
 }
 
 // After the level-2 counting sweep: positions, the cell lists (row-major cell ids), the level-3 pieces.
-// A one-block scan leaves the other 255 CUs idle for ten microseconds.  A caller's zero-fill can ride along:
-// workgroups 1 .. gridDim.x-1 of the launch clear `vecs` 16-byte words and leave, workgroup 0 scans.
-struct RiderFill {
-  uint4* at;
-  size_t vecs;
-};
-
-__device__ __forceinline__ void rider_fill(const RiderFill& f) {
-  const size_t stride = (size_t)(gridDim.x - 1) * kScanBlock;
-  for (size_t i = (size_t)(blockIdx.x - 1) * kScanBlock + threadIdx.x; i < f.vecs; i += stride) f.at[i] = make_uint4(0u, 0u, 0u, 0u);
-}
-
-inline unsigned rider_blocks(size_t vecs) {   // enough workgroups of 1024 threads for four stores per thread, at most 2 per CU
-  const size_t want = (vecs + 4 * kScanBlock - 1) / (4 * kScanBlock);
-  return (unsigned)(want < 512 ? want : 512);
-}
-
 __global__ void __launch_bounds__(kScanBlock) scan2_kernel(Grid g, const uint32_t* piece_first2, uint32_t* counts,
                                                            uint32_t* list_start, uint32_t* list_len,
                                                            uint32_t* piece_first, uint4* desc, RiderFill fill) {
@@ -818,9 +820,10 @@ int gsr::bin_lists(int P, uint32_t V, uint32_t N, uint32_t E1, uint32_t E2, int 
               "bin_lists: the zero-fill must be 16-byte aligned and a multiple of 16 bytes");
   const Grid g = make_grid(W, H);
   GSR_REQUIRE(g.sx <= 255 && g.sy <= 255, "bin_lists: image %dx%d too large", W, H);
-  // the rider is split between the two scans that have nothing else beside them
-  const size_t fill_vecs = zero_fill_bytes / 16;
-  const RiderFill fill2{(uint4*)zero_fill, fill_vecs / 2}, fill3{(uint4*)zero_fill + fill_vecs / 2, fill_vecs - fill_vecs / 2};
+  // the rider is split between the three scans, which have nothing else beside them
+  const size_t fill_vecs = zero_fill_bytes / 16, third = fill_vecs / 3;
+  const RiderFill fill1{(uint4*)zero_fill, third}, fill2{(uint4*)zero_fill + third, third},
+      fill3{(uint4*)zero_fill + 2 * third, fill_vecs - 2 * third};
   if (N == 0 || V == 0 || P == 0) {
     hipLaunchKernelGGL(zero_u32_kernel, dim3((unsigned)gsr::div_up(2 * g.tiles(), kBlock)), dim3(kBlock), 0, st, ranges,
                        (size_t)2 * g.tiles());
@@ -851,8 +854,9 @@ int gsr::bin_lists(int P, uint32_t V, uint32_t N, uint32_t E1, uint32_t E2, int 
     hipLaunchKernelGGL(count1_kernel, dim3(L.pieces1), dim3(Level<1>::kThreads), 0, st, a);
   else
     hipLaunchKernelGGL((partition_kernel<1, false>), dim3(L.pieces1), dim3(Level<1>::kThreads), 0, st, a);
-  hipLaunchKernelGGL(scan1_kernel, dim3(1), dim3(kScanBlock), 0, st, g, a.guard, status, V, a.counts, (uint32_t*)(base + L.list_start2),
-                     (uint32_t*)(base + L.list_len2), (uint32_t*)(base + L.piece_first2), (uint4*)(base + L.desc2));
+  hipLaunchKernelGGL(scan1_kernel, dim3(1 + rider_blocks(fill1.vecs)), dim3(kScanBlock), 0, st, g, a.guard, status, V, a.counts,
+                     (uint32_t*)(base + L.list_start2), (uint32_t*)(base + L.list_len2), (uint32_t*)(base + L.piece_first2),
+                     (uint4*)(base + L.desc2), fill1);
   if (g.supercells() <= 64)
     hipLaunchKernelGGL(write1_kernel, dim3(L.pieces1), dim3(Level<1>::kThreads), 0, st, a);
   else
