@@ -257,3 +257,51 @@ def test_the_forward_clears_the_backward_accumulator_beside_its_scans():
         assert (st.num_rendered > 0) == rendered
         assert st.dsplat is not None and st.dsplat.shape == (c.xyz.shape[0], 16)
         assert int(st.dsplat.view(torch.int32).abs().max()) == 0
+
+
+def test_two_host_threads_on_their_own_streams():
+    """Two host threads render different scenes at the same time, each on its own stream (forward through the
+    single call, backward after it).  The library keeps no state between calls and the binding's landing
+    buffer, status word, event and callbacks are per thread: every result equals the one the scene gives
+    alone."""
+    import threading
+    import diff_gaussian_rasterization as dgr
+    scenes = []
+    for seed, (W, H) in ((41, (400, 240)), (42, (320, 320))):
+        cloud, cam, bg, _ = make_scene(30_000, W, H, sh_degree=1, seed=seed)
+        s = _gpu_settings(cam, bg, 1, 1.0)
+        scenes.append((s, cloud.to("cuda")))
+
+    def run(s, c):
+        st = dgr.rasterize_forward(s, c.xyz, c.opacity, shs=c.features, scales=c.scaling, rotations=c.rotation,
+                                   prepare_backward=True)
+        d = torch.ones_like(st.color)
+        g = dgr.rasterize_backward(s, st, d, c.xyz, shs=c.features, scales=c.scaling, rotations=c.rotation)
+        return st.color.clone(), st.point_list.clone(), g["means3D"].clone()
+
+    alone = [run(s, c) for s, c in scenes]
+    torch.cuda.synchronize()
+    got = [[] for _ in scenes]
+    errors = []
+
+    def worker(k):
+        try:
+            stream = torch.cuda.Stream()
+            with torch.cuda.stream(stream):
+                for _ in range(20):
+                    got[k].append(run(*scenes[k]))
+            stream.synchronize()
+        except Exception as e:      # noqa: BLE001
+            errors.append(e)
+
+    threads = [threading.Thread(target=worker, args=(k,)) for k in range(len(scenes))]
+    for t in threads:
+        t.start()
+    for t in threads:
+        t.join()
+    torch.cuda.synchronize()
+    assert not errors, errors
+    for k, (color, plist, gmean) in enumerate(alone):
+        for c2, p2, g2 in got[k]:
+            assert torch.equal(c2, color) and torch.equal(p2, plist)
+            assert float((g2 - gmean).abs().max()) <= 2e-5 * float(gmean.abs().max())
