@@ -438,9 +438,21 @@ __global__ void __launch_bounds__(kBlock, 4) preprocess_bwd_kernel(BwdArgs a) {
   const bool valid = i < a.P;
   uint4 r3 = make_uint4(0u, 0u, 0u, 0u);
   if (valid) r3 = reinterpret_cast<const uint4*>(a.records)[(size_t)i * 4 + 3];
-  const bool vis = valid && (int)r3.w > 0;
+  bool vis = valid && (int)r3.w > 0;
   const float4* gsp = reinterpret_cast<const float4*>(a.dL_dsplat) + (size_t)i * (GSR_GRAD_WORDS / 4);
   float4 g0 = make_float4(0, 0, 0, 0), g1 = g0, g2 = g0;
+  float4 m0 = g0, m1 = g0;
+  if (vis) {
+    m0 = gsp[0]; m1 = gsp[1]; g2 = gsp[2];
+    // Every gradient of this kernel is linear in the nine sums the blend backward left for the Gaussian.  A
+    // Gaussian that no pixel blended (hidden behind saturated pixels: most of a dense scene) has nine zeros,
+    // hence zero gradients: it is treated like a culled one, and its parameters are not even loaded.
+    // (NaN != 0, so a poisoned row still takes the full path.)
+    const bool any = (m0.x != 0.f) | (m0.y != 0.f) | (m0.z != 0.f) | (m0.w != 0.f) | (m1.x != 0.f) | (m1.y != 0.f) |
+                     (m1.z != 0.f) | (m1.w != 0.f) | (g2.x != 0.f);
+    vis = any;
+    if (!any) g2 = make_float4(0, 0, 0, 0);
+  }
   if (vis) {
     // The blend backward leaves moments of u = dL/dG * G over each splat's pixels:
     //   (sum u, sum u dx, sum u dy, sum u dx^2, sum u dx dy, sum u dy^2, dr, dg, db)
@@ -448,8 +460,6 @@ __global__ void __launch_bounds__(kBlock, 4) preprocess_bwd_kernel(BwdArgs a) {
     //   dL/dopacity = sum u / o
     //   dL/dmean2D  = -(A sum u dx + B sum u dy) * W/2,  -(C sum u dy + B sum u dx) * H/2
     //   dL/d(A,B,C) = (-1/2 sum u dx^2, -sum u dx dy, -1/2 sum u dy^2)
-    const float4 m0 = gsp[0], m1 = gsp[1];
-    g2 = gsp[2];
     const uint4 r1 = reinterpret_cast<const uint4*>(a.records)[(size_t)i * 4 + 1];
     const float cA = __uint_as_float(r1.x), cB = __uint_as_float(r1.y), cC = __uint_as_float(r1.z);
     const float op = __uint_as_float(r1.w);
