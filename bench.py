@@ -58,7 +58,7 @@ WORKLOADS = {
     "c5": (6_000_000, 1920, 1080, 3, 0.5, None),
 }
 
-DOMINANT_STAGE = "blend_bwd"      # the longest kernel of the step on every workload here
+DOMINANT_STAGE = "blend_bwd"      # the longest kernel of the step on the headline workload: what the roofline object prices
 
 
 def algorithmic_bytes(P, N, W, H, M=16):
@@ -308,9 +308,13 @@ def main():
         N = m["visible"]
         st_N = _instances(dgr, scene)
         alg = algorithmic_bytes(P, st_N, W, H)
-        dominant = max(alg, key=lambda k: stage_ms.get(k, 0.0))
-        if dominant != DOMINANT_STAGE:
-            print(f"warning: {dominant} outlasts {DOMINANT_STAGE}", file=sys.stderr)
+        # The roofline object is about the blend backward, the longest kernel of the headline workload.  On a
+        # workload where another stage outlasts it (6M Gaussians: the per-Gaussian backward) that is said on
+        # stderr; that kernel skips the Gaussians no pixel blended, so its algorithmic bytes overstate its traffic.
+        longest = max(alg, key=lambda k: stage_ms.get(k, 0.0))
+        if longest != DOMINANT_STAGE:
+            print(f"note: {longest} ({stage_ms[longest]:.3f} ms) outlasts {DOMINANT_STAGE} on this workload", file=sys.stderr)
+        dominant = DOMINANT_STAGE
         dom_ms = stage_ms[dominant]
         achieved = alg[dominant] / (dom_ms * 1e-3) / 1e9
         kernels = {k: {"ms": round(stage_ms[k], 4), "algorithmic_GB": round(alg[k] / 1e9, 4) if k in alg else None,
