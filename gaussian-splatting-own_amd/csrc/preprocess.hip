@@ -436,22 +436,21 @@ __global__ void __launch_bounds__(kBlock, 4) preprocess_bwd_kernel(BwdArgs a) {
   extern __shared__ float rest_tile[];   // the block's rows of the SH gradient (raw mode: of _features_rest), stored coalesced
   const int i = blockIdx.x * kBlock + threadIdx.x;
   const bool valid = i < a.P;
-  uint4 r3 = make_uint4(0u, 0u, 0u, 0u);
-  if (valid) r3 = reinterpret_cast<const uint4*>(a.records)[(size_t)i * 4 + 3];
-  bool vis = valid && (int)r3.w > 0;
+  // Every gradient of this kernel is linear in the nine sums the blend backward left for the Gaussian.  A
+  // Gaussian that no pixel blended (culled, or hidden behind saturated pixels: most of a dense scene) has nine
+  // zeros, hence zero gradients: nothing else of it is loaded, not even its record.  (NaN != 0, so a poisoned
+  // row still takes the full path.)  A non-zero row of a Gaussian whose record says "culled" (only a caller
+  // that fills the rows itself can produce one) counts as zero too.
   const float4* gsp = reinterpret_cast<const float4*>(a.dL_dsplat) + (size_t)i * (GSR_GRAD_WORDS / 4);
   float4 g0 = make_float4(0, 0, 0, 0), g1 = g0, g2 = g0;
   float4 m0 = g0, m1 = g0;
-  if (vis) {
+  bool vis = false;
+  if (valid) {
     m0 = gsp[0]; m1 = gsp[1]; g2 = gsp[2];
-    // Every gradient of this kernel is linear in the nine sums the blend backward left for the Gaussian.  A
-    // Gaussian that no pixel blended (hidden behind saturated pixels: most of a dense scene) has nine zeros,
-    // hence zero gradients: it is treated like a culled one, and its parameters are not even loaded.
-    // (NaN != 0, so a poisoned row still takes the full path.)
-    const bool any = (m0.x != 0.f) | (m0.y != 0.f) | (m0.z != 0.f) | (m0.w != 0.f) | (m1.x != 0.f) | (m1.y != 0.f) |
-                     (m1.z != 0.f) | (m1.w != 0.f) | (g2.x != 0.f);
-    vis = any;
-    if (!any) g2 = make_float4(0, 0, 0, 0);
+    vis = (m0.x != 0.f) | (m0.y != 0.f) | (m0.z != 0.f) | (m0.w != 0.f) | (m1.x != 0.f) | (m1.y != 0.f) |
+          (m1.z != 0.f) | (m1.w != 0.f) | (g2.x != 0.f);
+    if (vis) vis = (int)a.records[(size_t)i * GSR_REC_WORDS + GSR_REC_RADIUS] > 0;
+    if (!vis) g2 = make_float4(0, 0, 0, 0);
   }
   if (vis) {
     // The blend backward leaves moments of u = dL/dG * G over each splat's pixels:
