@@ -413,6 +413,7 @@ __global__ void __launch_bounds__(kBlock) mark_visible_kernel(int P, const float
 }
 
 struct BwdArgs {
+  int sparse;   // the outputs are zero already: only Gaussians with gradients write
   int raw, n_rest; const float* shs_rest; const float* opacity_raw; float* dL_dshs_rest;
   int P, M, W, H;
   const float* means3D; const float* scales; const float* rotations; const float* shs;
@@ -434,7 +435,33 @@ __device__ __forceinline__ void store_f4(float* dst, const float* v) {
 template <int D>
 __global__ void __launch_bounds__(kBlock, 4) preprocess_bwd_kernel(BwdArgs a) {
   extern __shared__ float rest_tile[];   // the block's rows of the SH gradient (raw mode: of _features_rest), stored coalesced
-  const int i = blockIdx.x * kBlock + threadIdx.x;
+  int i = blockIdx.x * kBlock + threadIdx.x;
+  if (a.sparse) {
+    // The outputs are zero already, so only the Gaussians with gradients have anything to do, and in a dense
+    // scene those are a few per cent.  They are moved to the block's first lanes: one wave then runs the long
+    // arithmetic below for them instead of all four running it with two or three lanes switched on.
+    __shared__ int s_active[kBlock];
+    __shared__ int s_waves[kBlock / 64];
+    bool active = false;
+    if (i < a.P) {
+      const float4* row = reinterpret_cast<const float4*>(a.dL_dsplat) + (size_t)i * (GSR_GRAD_WORDS / 4);
+      const float4 r0 = row[0], r1 = row[1];
+      const float r2 = reinterpret_cast<const float*>(row)[8];
+      active = (r0.x != 0.f) | (r0.y != 0.f) | (r0.z != 0.f) | (r0.w != 0.f) | (r1.x != 0.f) | (r1.y != 0.f) |
+               (r1.z != 0.f) | (r1.w != 0.f) | (r2 != 0.f);
+    }
+    const unsigned long long votes = __ballot(active);
+    const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+    if (lane == 0) s_waves[wave] = __popcll(votes);
+    __syncthreads();
+    int before = 0, total = 0;
+#pragma unroll
+    for (int w = 0; w < kBlock / 64; w++) { before += w < wave ? s_waves[w] : 0; total += s_waves[w]; }
+    if (active) s_active[before + __popcll(votes & ((1ull << lane) - 1ull))] = i;
+    __syncthreads();
+    if ((int)threadIdx.x >= total) return;
+    i = s_active[threadIdx.x];
+  }
   const bool valid = i < a.P;
   // Every gradient of this kernel is linear in the nine sums the blend backward left for the Gaussian.  A
   // Gaussian that no pixel blended (culled, or hidden behind saturated pixels: most of a dense scene) has nine
@@ -649,7 +676,25 @@ __global__ void __launch_bounds__(kBlock, 4) preprocess_bwd_kernel(BwdArgs a) {
     dopac = dopac * (o * (1.0f - o));
   }
 
-  if (a.dL_dshs_rest) {
+  if (a.sparse) {
+    // the outputs were zero when the kernel started: only the Gaussians with gradients write, each its own rows
+    if (!vis) return;
+    if (a.dL_dshs_rest) {
+      const int R = a.n_rest * 3;
+      float* dst = a.dL_dshs_rest + (size_t)i * R;
+#pragma unroll
+      for (int k = 3; k < 48; k++)
+        if (k - 3 < R) dst[k - 3] = dsh[k];
+      float* dc = a.dL_dshs + (size_t)i * 3;
+      dc[0] = dsh[0]; dc[1] = dsh[1]; dc[2] = dsh[2];
+    } else if (a.dL_dshs) {
+      const int R = a.M * 3;
+      float* dst = a.dL_dshs + (size_t)i * R;
+#pragma unroll
+      for (int k = 0; k < 48; k++)
+        if (k < R) dst[k] = dsh[k];
+    }
+  } else if (a.dL_dshs_rest) {
     // each lane puts its row into the LDS tile, then the block stores the tile fully coalesced
     const int R = a.n_rest * 3;
     float* row = rest_tile + threadIdx.x * R;
@@ -773,7 +818,7 @@ extern "C" int gsr_preprocess_bwd(int P, int D, int M, const float* means3D, con
                                   float tanfovy, const uint32_t* records, const float* dL_dsplat,
                                   float* dL_dmeans3D, float* dL_dmeans2D, float* dL_dopacities,
                                   float* dL_dshs, float* dL_dcolors, float* dL_dscales,
-                                  float* dL_drotations, float* dL_dcov3D, void* stream) {
+                                  float* dL_drotations, float* dL_dcov3D, int outputs_zeroed, void* stream) {
   GSR_REQUIRE(P >= 0 && W > 0 && H > 0, "preprocess_bwd: bad sizes");
   if (P == 0) return GSR_OK;
   GSR_REQUIRE(means3D && viewmatrix && projmatrix && campos && records && dL_dsplat, "preprocess_bwd: null input");
@@ -787,13 +832,13 @@ extern "C" int gsr_preprocess_bwd(int P, int D, int M, const float* means3D, con
               "preprocess_bwd: scales/rotations and their gradients go together");
   GSR_REQUIRE(D >= 0 && D <= GSR_MAX_SH_DEGREE, "preprocess_bwd: SH degree %d unsupported", D);
   GSR_REQUIRE(!shs || (M >= (D + 1) * (D + 1) && M <= 16), "preprocess_bwd: M=%d unsupported for degree %d", M, D);
-  BwdArgs a{0, 0, nullptr, nullptr, nullptr, P, M, W, H, means3D, scales, rotations, shs, cov3D_precomp, viewmatrix, projmatrix, campos,
+  BwdArgs a{outputs_zeroed ? 1 : 0, 0, 0, nullptr, nullptr, nullptr, P, M, W, H, means3D, scales, rotations, shs, cov3D_precomp, viewmatrix, projmatrix, campos,
             scale_modifier, tanfovx, tanfovy, records, dL_dsplat, dL_dmeans3D, dL_dmeans2D, dL_dopacities,
             dL_dshs, dL_dcolors, dL_dscales, dL_drotations, dL_dcov3D};
   hipStream_t st = (hipStream_t)stream;
   dim3 grid(gsr::div_up(P, kBlock)), block(kBlock);
   const int d = shs ? D : 0;
-  const size_t lds = shs ? (size_t)kBlock * (M * 3 + 1) * sizeof(float) : 0;     // the block's tile of the SH gradient
+  const size_t lds = (shs && !a.sparse) ? (size_t)kBlock * (M * 3 + 1) * sizeof(float) : 0;     // the block's tile of the SH gradient
   switch (d) {
     case 0: hipLaunchKernelGGL(preprocess_bwd_kernel<0>, grid, block, lds, st, a); break;
     case 1: hipLaunchKernelGGL(preprocess_bwd_kernel<1>, grid, block, lds, st, a); break;
@@ -846,7 +891,7 @@ extern "C" int gsr_preprocess_bwd_raw(int P, int D, int n_rest, const float* xyz
                                       int H, float tanfovx, float tanfovy, const uint32_t* records,
                                       const float* dL_dsplat, float* dL_dxyz, float* dL_dmeans2D,
                                       float* dL_dopacity_raw, float* dL_dfeatures_dc, float* dL_dfeatures_rest,
-                                      float* dL_dscaling_raw, float* dL_drotation_raw, void* stream) {
+                                      float* dL_dscaling_raw, float* dL_drotation_raw, int outputs_zeroed, void* stream) {
   GSR_REQUIRE(P >= 0 && W > 0 && H > 0, "preprocess_bwd_raw: bad sizes");
   if (P == 0) return GSR_OK;
   GSR_REQUIRE(xyz && scaling_raw && rotation_raw && opacity_raw && features_dc && viewmatrix && projmatrix && campos &&
@@ -857,14 +902,14 @@ extern "C" int gsr_preprocess_bwd_raw(int P, int D, int n_rest, const float* xyz
   GSR_REQUIRE(n_rest >= (D + 1) * (D + 1) - 1 && n_rest <= 15 && (n_rest == 0 || (features_rest && dL_dfeatures_rest)),
               "preprocess_bwd_raw: n_rest=%d does not hold degree %d", n_rest, D);
   const bool split = n_rest > 0;
-  BwdArgs a{1, n_rest, split ? features_rest : nullptr, opacity_raw, split ? dL_dfeatures_rest : nullptr,
+  BwdArgs a{outputs_zeroed ? 1 : 0, 1, n_rest, split ? features_rest : nullptr, opacity_raw, split ? dL_dfeatures_rest : nullptr,
             P, 1 + n_rest, W, H, xyz, scaling_raw, rotation_raw, features_dc, nullptr, viewmatrix, projmatrix, campos,
             scale_modifier, tanfovx, tanfovy, records, dL_dsplat, dL_dxyz, dL_dmeans2D, dL_dopacity_raw,
             dL_dfeatures_dc, nullptr, dL_dscaling_raw, dL_drotation_raw, nullptr};
   hipStream_t st = (hipStream_t)stream;
   dim3 grid(gsr::div_up(P, kBlock)), block(kBlock);
   // the block's tile of the SH gradient: the rows of features_rest, or of features_dc when there is no rest tensor
-  const size_t lds = (size_t)kBlock * (split ? n_rest * 3 : 3 + 1) * sizeof(float);
+  const size_t lds = a.sparse ? 0 : (size_t)kBlock * (split ? n_rest * 3 : 3 + 1) * sizeof(float);
   switch (D) {
     case 0: hipLaunchKernelGGL(preprocess_bwd_kernel<0>, grid, block, lds, st, a); break;
     case 1: hipLaunchKernelGGL(preprocess_bwd_kernel<1>, grid, block, lds, st, a); break;

@@ -119,14 +119,14 @@ def _load():
     lib.gsr_event_destroy.argtypes, lib.gsr_event_destroy.restype = [vp], None
     lib.gsr_event_elapsed_ms.argtypes = [vp, vp, C.POINTER(C.c_float)]
     lib.gsr_preprocess_bwd.argtypes = [ci, ci, ci, vp, vp, cf, vp, vp, vp, vp, vp, vp, ci, ci, cf, cf, vp, vp,
-                                       vp, vp, vp, vp, vp, vp, vp, vp, vp]
+                                       vp, vp, vp, vp, vp, vp, vp, vp, ci, vp]
     lib.gsr_preprocess_fwd_raw.argtypes = [ci, ci, ci, vp, vp, cf, vp, vp, vp, vp, vp, vp, vp, ci, ci, cf, cf, ci,
                                            vp, vp, vp, vp, vp, vp, vp, vp, vp, vp]
     lib.gsr_forward_workspace_bytes.restype = C.c_size_t
     lib.gsr_forward_workspace_bytes.argtypes = [ci, ci, ci]
     lib.gsr_forward.argtypes = [C.POINTER(_ForwardArgs), _RESIZE_FN, vp, C.POINTER(_ForwardOut), vp]
     lib.gsr_preprocess_bwd_raw.argtypes = [ci, ci, ci, vp, vp, cf, vp, vp, vp, vp, vp, vp, vp, ci, ci, cf, cf,
-                                           vp, vp, vp, vp, vp, vp, vp, vp, vp, vp]
+                                           vp, vp, vp, vp, vp, vp, vp, vp, vp, ci, vp]
     return lib
 
 
@@ -322,7 +322,7 @@ class ForwardState:
     """Everything the forward leaves behind: op outputs, what backward needs,
     and the intermediate buffers the parity tests inspect."""
     __slots__ = ("P", "M", "D", "W", "H", "records", "radii", "depth_keys", "sorted_vals",
-                 "num_rendered", "num_visible", "dsplat", "visible", "point_list", "ranges", "tile_ids_sorted", "color", "final_T", "n_contrib",
+                 "num_rendered", "num_visible", "dsplat", "zeroed_grads", "visible", "point_list", "ranges", "tile_ids_sorted", "color", "final_T", "n_contrib",
                  "view", "proj", "campos", "bg")
 
     # views into the 64-byte records, named as the oracle names them
@@ -373,6 +373,40 @@ def _read_back_event(dev: torch.device):
         if not d["event"]:
             raise RuntimeError("libgsr_hip: " + _lib.gsr_last_error().decode())
     return d["event"]
+
+
+def _gradient_shapes(P: int, raw: bool, n_rest: int = 0, M: int = 0, colors: bool = False, cov3D: bool = False) -> dict:
+    """Name -> shape of the gradient tensors gsr_preprocess_bwd[_raw] writes for this combination of inputs."""
+    if raw:
+        shapes = dict(xyz=(P, 3), means2D=(P, 3), opacity=(P, 1), features_dc=(P, 1, 3), scaling=(P, 3), rotation=(P, 4))
+        if n_rest:
+            shapes["features_rest"] = (P, n_rest, 3)
+        return shapes
+    shapes = dict(means3D=(P, 3), means2D=(P, 3), opacities=(P, 1))
+    shapes["colors_precomp" if colors else "shs"] = (P, 3) if colors else (P, M, 3)
+    if cov3D:
+        shapes["cov3D_precomp"] = (P, 6)
+    else:
+        shapes["scales"], shapes["rotations"] = (P, 3), (P, 4)
+    return shapes
+
+
+def _carve_zero_block(P: int, shapes: dict, dev):
+    """One allocation for everything the backward wants zeroed before it starts: the (P,16) accumulator of the
+    blend backward and the gradient tensors of the per-Gaussian backward (which then writes only the rows
+    of Gaussians that have gradients).  Returns (block, accumulator, {name: tensor}); the pieces start on
+    256-byte boundaries and the block's size is a multiple of 256 bytes."""
+    def pad(n):
+        return (n + 63) // 64 * 64
+    sizes = {k: pad(int(torch.Size(v).numel())) for k, v in shapes.items()}
+    total = pad(P * GRAD_WORDS) + sum(sizes.values())
+    block = torch.empty((total,), dtype=torch.float32, device=dev)
+    at = pad(P * GRAD_WORDS)
+    views = {}
+    for k, v in shapes.items():
+        views[k] = block[at:at + int(torch.Size(v).numel())].view(v)
+        at += sizes[k]
+    return block, block[:P * GRAD_WORDS].view(P, GRAD_WORDS), views
 
 
 def _thread_callbacks():
@@ -431,10 +465,19 @@ def _forward_single_call(s, st, dev, means3D, opacities, shs, colors_precomp, sc
     a = _ForwardArgs()
     a.P, a.D, a.W, a.H = P, st.D, W, H
     p = lambda t: None if t is None else t.data_ptr()
-    if prepare_backward and hooks is None and P > 0:
-        # the accumulator of the blend backward is cleared by the library beside its one-block scan kernels
-        st.dsplat = torch.empty((P, GRAD_WORDS), dtype=torch.float32, device=dev)
-        a.zero_fill, a.zero_fill_bytes = st.dsplat.data_ptr(), P * GRAD_WORDS * 4
+    if prepare_backward and hooks is None and P > 0 and _RIDER:
+        # The accumulator of the blend backward and the gradient tensors of the per-Gaussian backward are cleared
+        # by the library beside its one-block scan kernels; the backward then writes only the rows of Gaussians
+        # that have gradients.
+        if raw is not None:
+            rest = raw["features_rest"]
+            shapes = _gradient_shapes(P, True, n_rest=0 if rest is None else rest.shape[1])
+        else:
+            shapes = _gradient_shapes(P, False, M=st.M, colors=shs is None, cov3D=cov3D_precomp is not None)
+        block, st.dsplat, views = _carve_zero_block(P, shapes, dev)
+        st.zeroed_grads = (shapes, views)
+        a.zero_fill, a.zero_fill_bytes = block.data_ptr(), block.numel() * 4
+        del block
     if raw is not None:
         r = {k: _f32(v, k) for k, v in raw.items()}
         n_rest = 0 if r["features_rest"] is None else r["features_rest"].shape[1]
@@ -523,6 +566,7 @@ def rasterize_forward(s: GaussianRasterizationSettings, means3D, opacities, shs=
     st.view, st.proj = _f32(s.viewmatrix, "viewmatrix"), _f32(s.projmatrix, "projmatrix")
     st.campos, st.bg = _f32(s.campos, "campos"), _f32(s.bg, "bg")
     st.dsplat = None
+    st.zeroed_grads = None
     ref_lists = int(REFERENCE_LISTS if reference_lists is None else reference_lists)
     # a timer that brackets stages with events needs the stage calls; one that only wants the blend kernels' own
     # events does not
@@ -660,24 +704,26 @@ def rasterize_backward(s: GaussianRasterizationSettings, st: ForwardState, grad_
     P = st.P
     if dsplat is None:
         dsplat = blend_backward(st, grad_color)
-    f = dict(dtype=torch.float32, device=dev)
-    g = dict(means3D=torch.empty((P, 3), **f), means2D=torch.empty((P, 3), **f), opacities=torch.empty((P, 1), **f),
-             shs=None, colors_precomp=None, scales=None, rotations=None, cov3D_precomp=None)
-    if shs is not None:
-        g["shs"] = torch.empty((P, st.M, 3), **f)
-    else:
-        g["colors_precomp"] = torch.empty((P, 3), **f)
-    if cov3D_precomp is not None:
-        g["cov3D_precomp"] = torch.empty((P, 6), **f)
-    else:
-        g["scales"], g["rotations"] = torch.empty((P, 3), **f), torch.empty((P, 4), **f)
+    shapes = _gradient_shapes(P, False, M=st.M, colors=shs is None, cov3D=cov3D_precomp is not None)
+    g = dict(shs=None, colors_precomp=None, scales=None, rotations=None, cov3D_precomp=None)
+    views = _take_zeroed_grads(st, shapes)
+    g.update(views if views is not None else {k: torch.empty(v, dtype=torch.float32, device=dev) for k, v in shapes.items()})
     if P > 0:
         _run("preprocess_bwd", _lib.gsr_preprocess_bwd, P, st.D, st.M, _ptr(means3D), _ptr(scales), float(s.scale_modifier), _ptr(rotations), _ptr(shs),
             _ptr(cov3D_precomp), _ptr(st.view), _ptr(st.proj), _ptr(st.campos), st.W, st.H, float(s.tanfovx),
             float(s.tanfovy), _ptr(st.records), _ptr(dsplat), _ptr(g["means3D"]), _ptr(g["means2D"]),
             _ptr(g["opacities"]), _ptr(g["shs"]), _ptr(g["colors_precomp"]), _ptr(g["scales"]), _ptr(g["rotations"]),
-            _ptr(g["cov3D_precomp"]), _stream())
+            _ptr(g["cov3D_precomp"]), int(views is not None), _stream())
     return g
+
+
+def _take_zeroed_grads(st: ForwardState, shapes: dict):
+    """The gradient tensors the forward had cleared, if they fit this backward (same tensors, same shapes) and
+    have not been handed out yet; good for one backward, like the accumulator."""
+    held, st.zeroed_grads = st.zeroed_grads, None
+    if held is None or held[0] != shapes:
+        return None
+    return held[1]
 
 
 def rasterize_backward_raw(s: GaussianRasterizationSettings, st: ForwardState, grad_color, xyz, raw: dict,
@@ -689,18 +735,18 @@ def rasterize_backward_raw(s: GaussianRasterizationSettings, st: ForwardState, g
     P = st.P
     if dsplat is None:
         dsplat = blend_backward(st, grad_color)
-    f = dict(dtype=torch.float32, device=dev)
     n_rest = 0 if r["features_rest"] is None else r["features_rest"].shape[1]
-    g = dict(xyz=torch.empty((P, 3), **f), means2D=torch.empty((P, 3), **f), opacity=torch.empty((P, 1), **f),
-             features_dc=torch.empty((P, 1, 3), **f),
-             features_rest=torch.empty((P, n_rest, 3), **f) if n_rest else None,
-             scaling=torch.empty((P, 3), **f), rotation=torch.empty((P, 4), **f))
+    shapes = _gradient_shapes(P, True, n_rest=n_rest)
+    views = _take_zeroed_grads(st, shapes)
+    g = dict(features_rest=None)
+    g.update(views if views is not None else {k: torch.empty(v, dtype=torch.float32, device=dev) for k, v in shapes.items()})
     if P > 0:
         _run("preprocess_bwd", _lib.gsr_preprocess_bwd_raw, P, st.D, n_rest, _ptr(xyz), _ptr(r["scaling"]),
              float(s.scale_modifier), _ptr(r["rotation"]), _ptr(r["opacity"]), _ptr(r["features_dc"]),
              _ptr(r["features_rest"]), _ptr(st.view), _ptr(st.proj), _ptr(st.campos), st.W, st.H, float(s.tanfovx),
              float(s.tanfovy), _ptr(st.records), _ptr(dsplat), _ptr(g["xyz"]), _ptr(g["means2D"]), _ptr(g["opacity"]),
-             _ptr(g["features_dc"]), _ptr(g["features_rest"]), _ptr(g["scaling"]), _ptr(g["rotation"]), _stream())
+             _ptr(g["features_dc"]), _ptr(g["features_rest"]), _ptr(g["scaling"]), _ptr(g["rotation"]),
+             int(views is not None), _stream())
     return g
 
 

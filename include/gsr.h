@@ -46,7 +46,7 @@
 extern "C" {
 #endif
 
-#define GSR_VERSION 3
+#define GSR_VERSION 4
 
 #define GSR_OK 0
 #define GSR_E_INVALID (-1)   /* bad argument (null pointer, negative size, unsupported M/D) */
@@ -340,7 +340,13 @@ int gsr_blend_bwd_timed(int W, int H, const uint32_t* ranges, const uint32_t* po
  * written (zeros for culled Gaussians): dL_dmeans3D (P,3); dL_dmeans2D (P,3)
  * = (x, y, 0); dL_dopacities (P,1); and, matching the inputs that were given,
  * dL_dshs (P,M,3) or dL_dcolors (P,3), dL_dscales (P,3) + dL_drotations (P,4)
- * or dL_dcov3D (P,6).  Pointers of the unused alternatives are NULL. */
+ * or dL_dcov3D (P,6).  Pointers of the unused alternatives are NULL.
+ * outputs_zeroed != 0: the caller promises that every output is zero already
+ * (e.g. cleared by gsr_forward's zero_fill rider).  Every gradient is linear in
+ * the Gaussian's row of dL_dsplat, so a Gaussian with an all-zero row (culled, or
+ * never blended because it is hidden: most Gaussians of a dense scene) has zero
+ * gradients; the kernel then writes only the rows of the others and skips the
+ * 248 bytes of zeros per Gaussian that dominate its traffic otherwise. */
 int gsr_preprocess_bwd(int P, int D, int M, const float* means3D, const float* scales,
                        float scale_modifier, const float* rotations, const float* shs,
                        const float* cov3D_precomp, const float* viewmatrix,
@@ -348,7 +354,7 @@ int gsr_preprocess_bwd(int P, int D, int M, const float* means3D, const float* s
                        float tanfovy, const uint32_t* records, const float* dL_dsplat,
                        float* dL_dmeans3D, float* dL_dmeans2D, float* dL_dopacities,
                        float* dL_dshs, float* dL_dcolors, float* dL_dscales,
-                       float* dL_drotations, float* dL_dcov3D, void* stream);
+                       float* dL_drotations, float* dL_dcov3D, int outputs_zeroed, void* stream);
 
 /* ---- Raw-parameter variants of the per-Gaussian stages -----------------------
  * The reference applies its activations in separate PyTorch kernels on every
@@ -374,7 +380,7 @@ int gsr_preprocess_bwd_raw(int P, int D, int n_rest, const float* xyz, const flo
                            int W, int H, float tanfovx, float tanfovy, const uint32_t* records,
                            const float* dL_dsplat, float* dL_dxyz, float* dL_dmeans2D,
                            float* dL_dopacity_raw, float* dL_dfeatures_dc, float* dL_dfeatures_rest,
-                           float* dL_dscaling_raw, float* dL_drotation_raw, void* stream);
+                           float* dL_dscaling_raw, float* dL_drotation_raw, int outputs_zeroed, void* stream);
 
 /* ---- Photometric loss ------------------------------------------------------
  * The step that follows the rasterizer in every training iteration

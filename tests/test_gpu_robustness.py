@@ -305,3 +305,52 @@ def test_two_host_threads_on_their_own_streams():
         for c2, p2, g2 in got[k]:
             assert torch.equal(c2, color) and torch.equal(p2, plist)
             assert float((g2 - gmean).abs().max()) <= 2e-5 * float(gmean.abs().max())
+
+
+@pytest.mark.parametrize("raw", [False, True])
+def test_backward_into_cleared_gradients_equals_the_dense_backward(raw):
+    """prepare_backward through the single call also clears the gradient tensors of the per-Gaussian backward,
+    which then writes only the rows of Gaussians that have gradients (outputs_zeroed).  Same numbers as the
+    backward that writes every row, for the reference's inputs and for raw parameters; Gaussians that are
+    culled or hidden have exact zeros either way (the allocator's cache is poisoned first)."""
+    import diff_gaussian_rasterization as dgr
+    from gsplat_host.model import GaussianParams
+    cloud, cam, bg, _ = make_scene(60_000, 480, 272, sh_degree=3, seed=17, bg=(0.2, 0.1, 0.0))
+    s = _gpu_settings(cam, bg, 3, 1.0)
+    c = cloud.to("cuda")
+    m = GaussianParams(cloud, device="cuda")
+    rawd = dict(features_dc=m._features_dc.detach(), features_rest=m._features_rest.detach(),
+                scaling=m._scaling.detach(), rotation=m._rotation.detach(), opacity=m._opacity.detach())
+    d = torch.randn((3, 272, 480), device="cuda", generator=torch.Generator(device="cuda").manual_seed(9))
+
+    def forward(prepare):
+        poison = torch.full((60_000 * 80,), float("nan"), device="cuda")
+        del poison
+        if raw:
+            return dgr.rasterize_forward(s, c.xyz, None, raw=rawd, prepare_backward=prepare, single_call=True)
+        return dgr.rasterize_forward(s, c.xyz, c.opacity, shs=c.features, scales=c.scaling, rotations=c.rotation,
+                                     prepare_backward=prepare, single_call=True)
+
+    def backward(st, sums):
+        if raw:
+            return dgr.rasterize_backward_raw(s, st, d, c.xyz, rawd, dsplat=sums)
+        return dgr.rasterize_backward(s, st, d, c.xyz, shs=c.features, scales=c.scaling, rotations=c.rotation, dsplat=sums)
+
+    prepared, plain = forward(True), forward(False)
+    assert prepared.zeroed_grads is not None and plain.zeroed_grads is None
+    sums = dgr.blend_backward(prepared, d)            # one set of sums for both: float atomics land in any order
+    sparse = backward(prepared, sums)
+    assert prepared.zeroed_grads is None              # handed out once
+    dense = backward(plain, sums)
+    torch.cuda.synchronize()
+    some = 0
+    for k, v in dense.items():
+        if v is None:
+            assert sparse[k] is None
+            continue
+        assert torch.equal(sparse[k], v), k           # the same arithmetic, only the untouched rows are not written
+        some += int((v.reshape(v.shape[0], -1).abs().sum(1) != 0).sum())
+    assert some > 0
+    again = backward(prepared, sums)                  # a second backward of the same state: the dense way
+    for k, v in dense.items():
+        assert v is None or torch.equal(again[k], v), k
