@@ -593,29 +593,12 @@ __device__ void build_pieces(uint32_t n, const uint32_t* list_start, const uint3
   }
 }
 
-// A one-block scan leaves the other 255 CUs idle for ten microseconds.  A caller's zero-fill can ride along:
-// workgroups 1 .. gridDim.x-1 of the launch clear `vecs` 16-byte words and leave, workgroup 0 scans.
-struct RiderFill {
-  uint4* at;
-  size_t vecs;
-};
-
-__device__ __forceinline__ void rider_fill(const RiderFill& f) {
-  const size_t stride = (size_t)(gridDim.x - 1) * kScanBlock;
-  for (size_t i = (size_t)(blockIdx.x - 1) * kScanBlock + threadIdx.x; i < f.vecs; i += stride) f.at[i] = make_uint4(0u, 0u, 0u, 0u);
-}
-
-inline unsigned rider_blocks(size_t vecs) {   // enough workgroups of 1024 threads for four stores per thread, at most 2 per CU
-  const size_t want = (vecs + 4 * kScanBlock - 1) / (4 * kScanBlock);
-  return (unsigned)(want < 512 ? want : 512);
-}
-
 // After the level-1 counting sweep: positions, the supercell lists, the level-2 pieces.
 __global__ void __launch_bounds__(kScanBlock) scan1_kernel(Grid g, Guard guard, uint32_t* status, uint32_t V,
                                                            uint32_t* counts, uint32_t* list_start,
                                                            uint32_t* list_len, uint32_t* piece_first, uint4* desc,
-                                                           RiderFill fill) {
-  if (blockIdx.x > 0) { rider_fill(fill); return; }
+                                                           gsr::RiderFill fill) {
+  if (blockIdx.x > 0) { gsr::rider_fill(fill, 1u); return; }
   __shared__ uint32_t s_wave[kScanBlock / 64];
   __shared__ uint32_t s_start[kFirstLds], s_len[kFirstLds], s_first[kFirstLds];
   const uint32_t F = (uint32_t)g.supercells(), np = (V + kPiece1 - 1) / kPiece1, slots = np * F;
@@ -647,8 +630,8 @@ __global__ void __launch_bounds__(kScanBlock) scan1_kernel(Grid g, Guard guard, 
 // After the level-2 counting sweep: positions, the cell lists (row-major cell ids), the level-3 pieces.
 __global__ void __launch_bounds__(kScanBlock) scan2_kernel(Grid g, const uint32_t* piece_first2, uint32_t* counts,
                                                            uint32_t* list_start, uint32_t* list_len,
-                                                           uint32_t* piece_first, uint4* desc, RiderFill fill) {
-  if (blockIdx.x > 0) { rider_fill(fill); return; }
+                                                           uint32_t* piece_first, uint4* desc, gsr::RiderFill fill) {
+  if (blockIdx.x > 0) { gsr::rider_fill(fill, 1u); return; }
   __shared__ uint32_t s_wave[kScanBlock / 64];
   __shared__ uint32_t s_start[kFirstLds], s_len[kFirstLds], s_first[kFirstLds];
   const uint32_t parents = (uint32_t)g.supercells(), cells = (uint32_t)g.cells();
@@ -689,8 +672,8 @@ constexpr int kTilesAtOnce = 4;
 
 __global__ void __launch_bounds__(kScanBlock) scan3_kernel(Grid g, const uint32_t* __restrict__ piece_first3,
                                                            uint32_t* __restrict__ counts, uint32_t* __restrict__ ranges,
-                                                           RiderFill fill) {
-  if (blockIdx.x > 0) { rider_fill(fill); return; }
+                                                           gsr::RiderFill fill) {
+  if (blockIdx.x > 0) { gsr::rider_fill(fill, 1u); return; }
   __shared__ uint32_t s_wave[kScanBlock / 64];
   const uint32_t parents = (uint32_t)g.cells();
   const uint32_t slots = piece_first3[parents] * kSuper;
@@ -822,7 +805,7 @@ int gsr::bin_lists(int P, uint32_t V, uint32_t N, uint32_t E1, uint32_t E2, int 
   GSR_REQUIRE(g.sx <= 255 && g.sy <= 255, "bin_lists: image %dx%d too large", W, H);
   // the rider is split between the three scans, which have nothing else beside them
   const size_t fill_vecs = zero_fill_bytes / 16, third = fill_vecs / 3;
-  const RiderFill fill1{(uint4*)zero_fill, third}, fill2{(uint4*)zero_fill + third, third},
+  const gsr::RiderFill fill1{(uint4*)zero_fill, third}, fill2{(uint4*)zero_fill + third, third},
       fill3{(uint4*)zero_fill + 2 * third, fill_vecs - 2 * third};
   if (N == 0 || V == 0 || P == 0) {
     hipLaunchKernelGGL(zero_u32_kernel, dim3((unsigned)gsr::div_up(2 * g.tiles(), kBlock)), dim3(kBlock), 0, st, ranges,
@@ -854,7 +837,7 @@ int gsr::bin_lists(int P, uint32_t V, uint32_t N, uint32_t E1, uint32_t E2, int 
     hipLaunchKernelGGL(count1_kernel, dim3(L.pieces1), dim3(Level<1>::kThreads), 0, st, a);
   else
     hipLaunchKernelGGL((partition_kernel<1, false>), dim3(L.pieces1), dim3(Level<1>::kThreads), 0, st, a);
-  hipLaunchKernelGGL(scan1_kernel, dim3(1 + rider_blocks(fill1.vecs)), dim3(kScanBlock), 0, st, g, a.guard, status, V, a.counts,
+  hipLaunchKernelGGL(scan1_kernel, dim3(1 + gsr::rider_blocks(fill1.vecs)), dim3(kScanBlock), 0, st, g, a.guard, status, V, a.counts,
                      (uint32_t*)(base + L.list_start2), (uint32_t*)(base + L.list_len2), (uint32_t*)(base + L.piece_first2),
                      (uint4*)(base + L.desc2), fill1);
   if (g.supercells() <= 64)
@@ -871,7 +854,7 @@ int gsr::bin_lists(int P, uint32_t V, uint32_t N, uint32_t E1, uint32_t E2, int 
   a.counts = (uint32_t*)(base + L.counts2);
   a.out64 = (u64*)(base + L.entries2);
   hipLaunchKernelGGL((partition_kernel<2, false>), dim3(L.max_pieces2), dim3(Level<2>::kThreads), 0, st, a);
-  hipLaunchKernelGGL(scan2_kernel, dim3(1 + rider_blocks(fill2.vecs)), dim3(kScanBlock), 0, st, g, a.piece_first, a.counts,
+  hipLaunchKernelGGL(scan2_kernel, dim3(1 + gsr::rider_blocks(fill2.vecs)), dim3(kScanBlock), 0, st, g, a.piece_first, a.counts,
                      (uint32_t*)(base + L.list_start3), (uint32_t*)(base + L.list_len3),
                      (uint32_t*)(base + L.piece_first3), (uint4*)(base + L.desc3), fill2);
   hipLaunchKernelGGL((partition_kernel<2, true>), dim3(L.max_pieces2), dim3(Level<2>::kThreads), 0, st, a);
@@ -886,7 +869,7 @@ int gsr::bin_lists(int P, uint32_t V, uint32_t N, uint32_t E1, uint32_t E2, int 
   a.out64 = nullptr;
   a.out32 = point_list;
   hipLaunchKernelGGL((partition_kernel<3, false>), dim3(L.max_pieces3), dim3(Level<3>::kThreads), 0, st, a);
-  hipLaunchKernelGGL(scan3_kernel, dim3(1 + rider_blocks(fill3.vecs)), dim3(kScanBlock), 0, st, g, a.piece_first, a.counts,
+  hipLaunchKernelGGL(scan3_kernel, dim3(1 + gsr::rider_blocks(fill3.vecs)), dim3(kScanBlock), 0, st, g, a.piece_first, a.counts,
                      ranges, fill3);
   hipLaunchKernelGGL((partition_kernel<3, true>), dim3(L.max_pieces3), dim3(Level<3>::kThreads), 0, st, a);
   if (tile_ids_sorted)

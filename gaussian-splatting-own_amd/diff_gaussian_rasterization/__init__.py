@@ -391,22 +391,39 @@ def _gradient_shapes(P: int, raw: bool, n_rest: int = 0, M: int = 0, colors: boo
     return shapes
 
 
+_carve_plans: dict = {}
+
+
 def _carve_zero_block(P: int, shapes: dict, dev):
     """One allocation for everything the backward wants zeroed before it starts: the (P,16) accumulator of the
     blend backward and the gradient tensors of the per-Gaussian backward (which then writes only the rows
     of Gaussians that have gradients).  Returns (block, accumulator, {name: tensor}); the pieces start on
-    256-byte boundaries and the block's size is a multiple of 256 bytes."""
-    def pad(n):
-        return (n + 63) // 64 * 64
-    sizes = {k: pad(int(torch.Size(v).numel())) for k, v in shapes.items()}
-    total = pad(P * GRAD_WORDS) + sum(sizes.values())
+    256-byte boundaries.  One as_strided per piece, from a plan kept per (P, shapes): this runs every step,
+    and at a hundred thousand Gaussians the step is short enough for a dozen extra tensor operations to show."""
+    key = (P, tuple(shapes.items()))
+    plan = _carve_plans.get(key)
+    if plan is None:
+        def pad(n):
+            return (n + 63) // 64 * 64
+
+        def strides(shape):
+            out, run = [], 1
+            for d in reversed(shape):
+                out.append(run)
+                run *= d
+            return tuple(reversed(out))
+        at = pad(P * GRAD_WORDS)
+        pieces = []
+        for k, v in shapes.items():
+            pieces.append((k, tuple(v), strides(v), at))
+            at += pad(int(torch.Size(v).numel()))
+        if len(_carve_plans) > 64:
+            _carve_plans.clear()
+        plan = _carve_plans[key] = (at, pieces)
+    total, pieces = plan
     block = torch.empty((total,), dtype=torch.float32, device=dev)
-    at = pad(P * GRAD_WORDS)
-    views = {}
-    for k, v in shapes.items():
-        views[k] = block[at:at + int(torch.Size(v).numel())].view(v)
-        at += sizes[k]
-    return block, block[:P * GRAD_WORDS].view(P, GRAD_WORDS), views
+    views = {k: torch.as_strided(block, shape, stride, off) for k, shape, stride, off in pieces}
+    return block, torch.as_strided(block, (P, GRAD_WORDS), (GRAD_WORDS, 1), 0), views
 
 
 def _thread_callbacks():
