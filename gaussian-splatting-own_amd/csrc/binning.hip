@@ -596,9 +596,7 @@ __device__ void build_pieces(uint32_t n, const uint32_t* list_start, const uint3
 // After the level-1 counting sweep: positions, the supercell lists, the level-2 pieces.
 __global__ void __launch_bounds__(kScanBlock) scan1_kernel(Grid g, Guard guard, uint32_t* status, uint32_t V,
                                                            uint32_t* counts, uint32_t* list_start,
-                                                           uint32_t* list_len, uint32_t* piece_first, uint4* desc,
-                                                           gsr::RiderFill fill) {
-  if (blockIdx.x > 0) { gsr::rider_fill(fill, 1u); return; }
+                                                           uint32_t* list_len, uint32_t* piece_first, uint4* desc) {
   __shared__ uint32_t s_wave[kScanBlock / 64];
   __shared__ uint32_t s_start[kFirstLds], s_len[kFirstLds], s_first[kFirstLds];
   const uint32_t F = (uint32_t)g.supercells(), np = (V + kPiece1 - 1) / kPiece1, slots = np * F;
@@ -630,8 +628,7 @@ __global__ void __launch_bounds__(kScanBlock) scan1_kernel(Grid g, Guard guard, 
 // After the level-2 counting sweep: positions, the cell lists (row-major cell ids), the level-3 pieces.
 __global__ void __launch_bounds__(kScanBlock) scan2_kernel(Grid g, const uint32_t* piece_first2, uint32_t* counts,
                                                            uint32_t* list_start, uint32_t* list_len,
-                                                           uint32_t* piece_first, uint4* desc, gsr::RiderFill fill) {
-  if (blockIdx.x > 0) { gsr::rider_fill(fill, 1u); return; }
+                                                           uint32_t* piece_first, uint4* desc) {
   __shared__ uint32_t s_wave[kScanBlock / 64];
   __shared__ uint32_t s_start[kFirstLds], s_len[kFirstLds], s_first[kFirstLds];
   const uint32_t parents = (uint32_t)g.supercells(), cells = (uint32_t)g.cells();
@@ -671,9 +668,7 @@ __global__ void __launch_bounds__(kScanBlock) scan2_kernel(Grid g, const uint32_
 constexpr int kTilesAtOnce = 4;
 
 __global__ void __launch_bounds__(kScanBlock) scan3_kernel(Grid g, const uint32_t* __restrict__ piece_first3,
-                                                           uint32_t* __restrict__ counts, uint32_t* __restrict__ ranges,
-                                                           gsr::RiderFill fill) {
-  if (blockIdx.x > 0) { gsr::rider_fill(fill, 1u); return; }
+                                                           uint32_t* __restrict__ counts, uint32_t* __restrict__ ranges) {
   __shared__ uint32_t s_wave[kScanBlock / 64];
   const uint32_t parents = (uint32_t)g.cells();
   const uint32_t slots = piece_first3[parents] * kSuper;
@@ -793,25 +788,18 @@ extern "C" const uint32_t* gsr_bin_sort_error_word(const void* sort_scratch) {
   return sort_scratch ? gsr::depth_sort_error_word(sort_scratch) : nullptr;
 }
 
-int gsr::bin_lists(int P, uint32_t V, uint32_t N, uint32_t E1, uint32_t E2, int W, int H, const uint64_t* sorted_vals,
-                   uint32_t* point_list, uint32_t* ranges, uint32_t* tile_ids_sorted, const uint32_t* sort_error,
-                   const uint32_t* totals, uint32_t* status, void* scratch, size_t scratch_bytes, void* zero_fill,
-                   size_t zero_fill_bytes, hipStream_t st) {
+extern "C" int gsr_bin_lists(int P, uint32_t V, uint32_t N, uint32_t E1, uint32_t E2, int W, int H,
+                             const uint64_t* sorted_vals, uint32_t* point_list, uint32_t* ranges,
+                             uint32_t* tile_ids_sorted, const uint32_t* sort_error, const uint32_t* totals,
+                             uint32_t* status, void* scratch, size_t scratch_bytes, void* stream) {
+  const hipStream_t st = (hipStream_t)stream;
   GSR_REQUIRE(P >= 0 && W > 0 && H > 0, "bin_lists: bad sizes");
   GSR_REQUIRE(ranges, "bin_lists: null ranges");
-  GSR_REQUIRE(zero_fill_bytes == 0 || (zero_fill && ((uintptr_t)zero_fill & 15) == 0 && zero_fill_bytes % 16 == 0),
-              "bin_lists: the zero-fill must be 16-byte aligned and a multiple of 16 bytes");
   const Grid g = make_grid(W, H);
   GSR_REQUIRE(g.sx <= 255 && g.sy <= 255, "bin_lists: image %dx%d too large", W, H);
-  // the rider is split between the three scans, which have nothing else beside them
-  const size_t fill_vecs = zero_fill_bytes / 16, third = fill_vecs / 3;
-  const gsr::RiderFill fill1{(uint4*)zero_fill, third}, fill2{(uint4*)zero_fill + third, third},
-      fill3{(uint4*)zero_fill + 2 * third, fill_vecs - 2 * third};
   if (N == 0 || V == 0 || P == 0) {
     hipLaunchKernelGGL(zero_u32_kernel, dim3((unsigned)gsr::div_up(2 * g.tiles(), kBlock)), dim3(kBlock), 0, st, ranges,
                        (size_t)2 * g.tiles());
-    if (fill_vecs)
-      hipLaunchKernelGGL(zero_u32_kernel, dim3(1024), dim3(kBlock), 0, st, (uint32_t*)zero_fill, fill_vecs * 4);
     return gsr::check_launch("bin_lists");
   }
   GSR_REQUIRE(sorted_vals && point_list && scratch, "bin_lists: null pointer");
@@ -837,9 +825,9 @@ int gsr::bin_lists(int P, uint32_t V, uint32_t N, uint32_t E1, uint32_t E2, int 
     hipLaunchKernelGGL(count1_kernel, dim3(L.pieces1), dim3(Level<1>::kThreads), 0, st, a);
   else
     hipLaunchKernelGGL((partition_kernel<1, false>), dim3(L.pieces1), dim3(Level<1>::kThreads), 0, st, a);
-  hipLaunchKernelGGL(scan1_kernel, dim3(1 + gsr::rider_blocks(fill1.vecs)), dim3(kScanBlock), 0, st, g, a.guard, status, V, a.counts,
+  hipLaunchKernelGGL(scan1_kernel, dim3(1), dim3(kScanBlock), 0, st, g, a.guard, status, V, a.counts,
                      (uint32_t*)(base + L.list_start2), (uint32_t*)(base + L.list_len2), (uint32_t*)(base + L.piece_first2),
-                     (uint4*)(base + L.desc2), fill1);
+                     (uint4*)(base + L.desc2));
   if (g.supercells() <= 64)
     hipLaunchKernelGGL(write1_kernel, dim3(L.pieces1), dim3(Level<1>::kThreads), 0, st, a);
   else
@@ -854,9 +842,9 @@ int gsr::bin_lists(int P, uint32_t V, uint32_t N, uint32_t E1, uint32_t E2, int 
   a.counts = (uint32_t*)(base + L.counts2);
   a.out64 = (u64*)(base + L.entries2);
   hipLaunchKernelGGL((partition_kernel<2, false>), dim3(L.max_pieces2), dim3(Level<2>::kThreads), 0, st, a);
-  hipLaunchKernelGGL(scan2_kernel, dim3(1 + gsr::rider_blocks(fill2.vecs)), dim3(kScanBlock), 0, st, g, a.piece_first, a.counts,
+  hipLaunchKernelGGL(scan2_kernel, dim3(1), dim3(kScanBlock), 0, st, g, a.piece_first, a.counts,
                      (uint32_t*)(base + L.list_start3), (uint32_t*)(base + L.list_len3),
-                     (uint32_t*)(base + L.piece_first3), (uint4*)(base + L.desc3), fill2);
+                     (uint32_t*)(base + L.piece_first3), (uint4*)(base + L.desc3));
   hipLaunchKernelGGL((partition_kernel<2, true>), dim3(L.max_pieces2), dim3(Level<2>::kThreads), 0, st, a);
   rc = gsr::check_launch("bin_lists: level 2");
   if (rc) return rc;
@@ -869,18 +857,10 @@ int gsr::bin_lists(int P, uint32_t V, uint32_t N, uint32_t E1, uint32_t E2, int 
   a.out64 = nullptr;
   a.out32 = point_list;
   hipLaunchKernelGGL((partition_kernel<3, false>), dim3(L.max_pieces3), dim3(Level<3>::kThreads), 0, st, a);
-  hipLaunchKernelGGL(scan3_kernel, dim3(1 + gsr::rider_blocks(fill3.vecs)), dim3(kScanBlock), 0, st, g, a.piece_first, a.counts,
-                     ranges, fill3);
+  hipLaunchKernelGGL(scan3_kernel, dim3(1), dim3(kScanBlock), 0, st, g, a.piece_first, a.counts,
+                     ranges);
   hipLaunchKernelGGL((partition_kernel<3, true>), dim3(L.max_pieces3), dim3(Level<3>::kThreads), 0, st, a);
   if (tile_ids_sorted)
     hipLaunchKernelGGL(fill_tile_ids_kernel, dim3(g.tiles()), dim3(kBlock), 0, st, ranges, tile_ids_sorted);
   return gsr::check_launch("bin_lists: level 3");
-}
-
-extern "C" int gsr_bin_lists(int P, uint32_t V, uint32_t N, uint32_t E1, uint32_t E2, int W, int H,
-                             const uint64_t* sorted_vals, uint32_t* point_list, uint32_t* ranges,
-                             uint32_t* tile_ids_sorted, const uint32_t* sort_error, const uint32_t* totals,
-                             uint32_t* status, void* scratch, size_t scratch_bytes, void* stream) {
-  return gsr::bin_lists(P, V, N, E1, E2, W, H, sorted_vals, point_list, ranges, tile_ids_sorted, sort_error, totals, status,
-                        scratch, scratch_bytes, nullptr, 0, (hipStream_t)stream);
 }

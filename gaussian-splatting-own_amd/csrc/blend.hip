@@ -128,11 +128,33 @@ __device__ __forceinline__ void stage_record(StagedBack* slot, const uint4 r0, c
 // ---------------------------------------------------------------------------
 // forward
 // ---------------------------------------------------------------------------
+// A zero-fill the blend kernels carry: every workgroup clears `share` 16-byte vectors of the caller's memory
+// as its last act, while the kernels leave HBM almost idle.  (Ahead of the workgroup's own work the same
+// stores cost the backward twice as much: its next wait for a load then also waits for them.)
+struct ShareFill {
+  uint4* at;
+  size_t vecs;
+  uint32_t share;   // vectors per workgroup: ceil(vecs / workgroups)
+};
+
+__device__ __forceinline__ void fill_my_share(const ShareFill& f) {
+  if (f.vecs == 0) return;
+  const size_t first = ((size_t)blockIdx.y * gridDim.x + blockIdx.x) * f.share;
+  const size_t end = first + f.share < f.vecs ? first + f.share : f.vecs;
+  for (size_t i = first + threadIdx.x; i < end; i += 256) f.at[i] = make_uint4(0u, 0u, 0u, 0u);   // workgroups of 256
+}
+
+inline ShareFill share_fill(void* zero_fill, size_t bytes, dim3 grid) {
+  const size_t vecs = bytes / 16, groups = (size_t)grid.x * grid.y;
+  return ShareFill{(uint4*)zero_fill, vecs, (uint32_t)((vecs + groups - 1) / groups)};
+}
+
 __global__ void __launch_bounds__(256) blend_fwd_kernel(int W, int H, const uint2* __restrict__ ranges,
                                                         const uint32_t* __restrict__ point_list,
                                                         const uint4* __restrict__ records,
                                                         const float* __restrict__ bg, float* __restrict__ out_color,
-                                                        float* __restrict__ final_T, uint32_t* __restrict__ n_contrib) {
+                                                        float* __restrict__ final_T, uint32_t* __restrict__ n_contrib,
+                                                        ShareFill fill) {
   __shared__ Staged s_splat[kBatch];
   __shared__ unsigned long long s_mask[4][4];  // [quadrant][staging wave]
 
@@ -221,6 +243,7 @@ __global__ void __launch_bounds__(256) blend_fwd_kernel(int W, int H, const uint
     out_color[plane + pix] = C1 + T * bg[1];
     out_color[2 * plane + pix] = C2 + T * bg[2];
   }
+  fill_my_share(fill);
 }
 
 // ---------------------------------------------------------------------------
@@ -283,7 +306,8 @@ __global__ void __launch_bounds__(256) blend_bwd_kernel(int W, int H, const uint
                                                         const float* __restrict__ final_T,
                                                         const uint32_t* __restrict__ n_contrib,
                                                         const float* __restrict__ dL_dpix,
-                                                        float* __restrict__ dL_dsplat) {
+                                                        float* __restrict__ dL_dsplat,
+                                                        ShareFill fill) {
   __shared__ StagedBack s_splat[kBatch];
   __shared__ unsigned long long s_mask[4][4];
   __shared__ int s_last[4];
@@ -310,7 +334,7 @@ __global__ void __launch_bounds__(256) blend_bwd_kernel(int W, int H, const uint
   __syncthreads();
   const int wave_last = __builtin_amdgcn_readfirstlane(wl);
   const int tile_last = max(max(s_last[0], s_last[1]), max(s_last[2], s_last[3]));
-  if (tile_last == 0 || total == 0) return;
+  if (tile_last == 0 || total == 0) { fill_my_share(fill); return; }
 
   // acc = colour composited behind the current splat (everything already visited in this
   // back-to-front walk), per channel.
@@ -404,6 +428,7 @@ __global__ void __launch_bounds__(256) blend_bwd_kernel(int W, int H, const uint
       }
     }
   }
+  fill_my_share(fill);
 }
 
 }  // namespace
@@ -413,33 +438,40 @@ namespace {
 // With events the launch goes through hipExtLaunchKernelGGL, which stamps them with the kernel's own
 // start and end (what a profiler's kernel trace reports), instead of with the stream's progress around it.
 int launch_blend_fwd(int W, int H, const uint32_t* ranges, const uint32_t* point_list, const uint32_t* records,
-                     const float* bg, float* out_color, float* final_T, uint32_t* n_contrib, hipEvent_t start,
-                     hipEvent_t stop, void* stream) {
+                     const float* bg, float* out_color, float* final_T, uint32_t* n_contrib, void* zero_fill,
+                     size_t zero_fill_bytes, hipEvent_t start, hipEvent_t stop, void* stream) {
   GSR_REQUIRE(W > 0 && H > 0, "blend_fwd: bad image size %dx%d", W, H);
+  GSR_REQUIRE(zero_fill_bytes == 0 || (zero_fill && ((uintptr_t)zero_fill & 15) == 0 && zero_fill_bytes % 16 == 0),
+              "blend_fwd: zero_fill must be 16-byte aligned and a multiple of 16 bytes");
   GSR_REQUIRE(ranges && bg && out_color && final_T && n_contrib, "blend_fwd: null pointer");
   dim3 grid(gsr::div_up(W, GSR_TILE_X), gsr::div_up(H, GSR_TILE_Y)), block(256);
+  const ShareFill fill = share_fill(zero_fill, zero_fill_bytes, grid);
   if (start || stop)
     hipExtLaunchKernelGGL(blend_fwd_kernel, grid, block, 0, (hipStream_t)stream, start, stop, 0, W, H, (const uint2*)ranges,
-                          point_list, (const uint4*)records, bg, out_color, final_T, n_contrib);
+                          point_list, (const uint4*)records, bg, out_color, final_T, n_contrib, fill);
   else
     hipLaunchKernelGGL(blend_fwd_kernel, grid, block, 0, (hipStream_t)stream, W, H, (const uint2*)ranges, point_list,
-                       (const uint4*)records, bg, out_color, final_T, n_contrib);
+                       (const uint4*)records, bg, out_color, final_T, n_contrib, fill);
   return gsr::check_launch("blend_fwd");
 }
 
 int launch_blend_bwd(int W, int H, const uint32_t* ranges, const uint32_t* point_list, const uint32_t* records,
                      const float* bg, const float* final_T, const uint32_t* n_contrib, const float* dL_dpix,
-                     float* dL_dsplat, hipEvent_t start, hipEvent_t stop, void* stream) {
+                     float* dL_dsplat, void* zero_fill, size_t zero_fill_bytes, hipEvent_t start, hipEvent_t stop,
+                     void* stream) {
   GSR_REQUIRE(W > 0 && H > 0, "blend_bwd: bad image size %dx%d", W, H);
+  GSR_REQUIRE(zero_fill_bytes == 0 || (zero_fill && ((uintptr_t)zero_fill & 15) == 0 && zero_fill_bytes % 16 == 0),
+              "blend_bwd: zero_fill must be 16-byte aligned and a multiple of 16 bytes");
   GSR_REQUIRE(ranges && bg && final_T && n_contrib && dL_dpix && dL_dsplat, "blend_bwd: null pointer");
   GSR_REQUIRE(((uintptr_t)dL_dsplat & 63) == 0, "blend_bwd: dL_dsplat must be 64-byte aligned");
   dim3 grid(gsr::div_up(W, GSR_TILE_X), gsr::div_up(H, GSR_TILE_Y)), block(256);
+  const ShareFill fill = share_fill(zero_fill, zero_fill_bytes, grid);
   if (start || stop)
     hipExtLaunchKernelGGL(blend_bwd_kernel, grid, block, 0, (hipStream_t)stream, start, stop, 0, W, H, (const uint2*)ranges,
-                          point_list, (const uint4*)records, bg, final_T, n_contrib, dL_dpix, dL_dsplat);
+                          point_list, (const uint4*)records, bg, final_T, n_contrib, dL_dpix, dL_dsplat, fill);
   else
     hipLaunchKernelGGL(blend_bwd_kernel, grid, block, 0, (hipStream_t)stream, W, H, (const uint2*)ranges, point_list,
-                       (const uint4*)records, bg, final_T, n_contrib, dL_dpix, dL_dsplat);
+                       (const uint4*)records, bg, final_T, n_contrib, dL_dpix, dL_dsplat, fill);
   return gsr::check_launch("blend_bwd");
 }
 
@@ -448,27 +480,43 @@ int launch_blend_bwd(int W, int H, const uint32_t* ranges, const uint32_t* point
 extern "C" int gsr_blend_fwd(int W, int H, const uint32_t* ranges, const uint32_t* point_list,
                              const uint32_t* records, const float* bg, float* out_color, float* final_T,
                              uint32_t* n_contrib, void* stream) {
-  return launch_blend_fwd(W, H, ranges, point_list, records, bg, out_color, final_T, n_contrib, nullptr, nullptr, stream);
+  return launch_blend_fwd(W, H, ranges, point_list, records, bg, out_color, final_T, n_contrib, nullptr, 0, nullptr, nullptr,
+                          stream);
 }
 
 extern "C" int gsr_blend_bwd(int W, int H, const uint32_t* ranges, const uint32_t* point_list,
                              const uint32_t* records, const float* bg, const float* final_T,
                              const uint32_t* n_contrib, const float* dL_dpix, float* dL_dsplat, void* stream) {
-  return launch_blend_bwd(W, H, ranges, point_list, records, bg, final_T, n_contrib, dL_dpix, dL_dsplat, nullptr, nullptr,
-                          stream);
+  return launch_blend_bwd(W, H, ranges, point_list, records, bg, final_T, n_contrib, dL_dpix, dL_dsplat, nullptr, 0,
+                          nullptr, nullptr, stream);
 }
 
 extern "C" int gsr_blend_fwd_timed(int W, int H, const uint32_t* ranges, const uint32_t* point_list,
                                    const uint32_t* records, const float* bg, float* out_color, float* final_T,
                                    uint32_t* n_contrib, void* start_event, void* stop_event, void* stream) {
-  return launch_blend_fwd(W, H, ranges, point_list, records, bg, out_color, final_T, n_contrib, (hipEvent_t)start_event,
-                          (hipEvent_t)stop_event, stream);
+  return launch_blend_fwd(W, H, ranges, point_list, records, bg, out_color, final_T, n_contrib, nullptr, 0,
+                          (hipEvent_t)start_event, (hipEvent_t)stop_event, stream);
+}
+
+int gsr::blend_fwd(int W, int H, const uint32_t* ranges, const uint32_t* point_list, const uint32_t* records,
+                   const float* bg, float* out_color, float* final_T, uint32_t* n_contrib, void* zero_fill,
+                   size_t zero_fill_bytes, void* start_event, void* stop_event, hipStream_t stream) {
+  return launch_blend_fwd(W, H, ranges, point_list, records, bg, out_color, final_T, n_contrib, zero_fill, zero_fill_bytes,
+                          (hipEvent_t)start_event, (hipEvent_t)stop_event, stream);
 }
 
 extern "C" int gsr_blend_bwd_timed(int W, int H, const uint32_t* ranges, const uint32_t* point_list,
                                    const uint32_t* records, const float* bg, const float* final_T,
                                    const uint32_t* n_contrib, const float* dL_dpix, float* dL_dsplat,
                                    void* start_event, void* stop_event, void* stream) {
-  return launch_blend_bwd(W, H, ranges, point_list, records, bg, final_T, n_contrib, dL_dpix, dL_dsplat,
+  return launch_blend_bwd(W, H, ranges, point_list, records, bg, final_T, n_contrib, dL_dpix, dL_dsplat, nullptr, 0,
                           (hipEvent_t)start_event, (hipEvent_t)stop_event, stream);
+}
+
+extern "C" int gsr_blend_bwd_fill(int W, int H, const uint32_t* ranges, const uint32_t* point_list,
+                                  const uint32_t* records, const float* bg, const float* final_T,
+                                  const uint32_t* n_contrib, const float* dL_dpix, float* dL_dsplat, void* zero_fill,
+                                  size_t zero_fill_bytes, void* start_event, void* stop_event, void* stream) {
+  return launch_blend_bwd(W, H, ranges, point_list, records, bg, final_T, n_contrib, dL_dpix, dL_dsplat, zero_fill,
+                          zero_fill_bytes, (hipEvent_t)start_event, (hipEvent_t)stop_event, stream);
 }

@@ -107,9 +107,7 @@ __global__ void __launch_bounds__(256) sort_clear_kernel(uint32_t* __restrict__ 
 // Digit histograms of all four passes over the keys of visible Gaussians, and their number.
 __global__ void __launch_bounds__(kThreads) sort_histogram_kernel(const uint32_t* __restrict__ keys, uint32_t P,
                                                                   uint32_t* __restrict__ hist,
-                                                                  uint32_t* __restrict__ ctl, uint32_t own_blocks,
-                                                                  gsr::RiderFill fill) {
-  if (blockIdx.x >= own_blocks) { gsr::rider_fill(fill, own_blocks); return; }
+                                                                  uint32_t* __restrict__ ctl) {
   __shared__ uint32_t s_h[kHistCopyWords];
   __shared__ uint32_t s_valid;
   s_h[threadIdx.x] = 0u;
@@ -171,8 +169,6 @@ struct PassArgs {
   uint32_t P;
   uint32_t spin_limit;    // look-back steps before a workgroup gives up and flags the sort as failed
   uint32_t static_order;  // workgroup b takes chunk b (the whole grid is resident at once) instead of drawing a ticket
-  uint32_t workgroups;    // of the sort itself; the launch's further workgroups carry the rider
-  gsr::RiderFill fill;
 };
 
 // Look-back over the counts published at states[q][t] for q = p, p-1, ..., stop, newest first: a window of
@@ -249,7 +245,6 @@ __global__ void __launch_bounds__(kThreads) sort_pass_kernel(PassArgs a) {
   __shared__ uint32_t s_misc[16];
   constexpr int kShift = 8 * PASS;
   const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
-  if (blockIdx.x >= a.workgroups) { gsr::rider_fill(a.fill, a.workgroups); return; }
 
   // A pass that follows one in which a look-back gave up would rank keys that were never written
   // against the up-front histograms, and its positions would no longer be bounded by the key count:
@@ -491,13 +486,8 @@ size_t depth_sort_bytes(int P) { return P > 0 ? layout((uint32_t)P).total : 256;
 // sorted_vals[0 .. visible) = the values of the keys != 0xFFFFFFFF in ascending key order, equal
 // keys in input order; the rest of sorted_vals is left untouched.
 int depth_sort(int P, const uint32_t* keys, const uint64_t* vals, uint64_t* sorted_vals, void* scratch, hipStream_t st,
-               const SortMirror* mirror, void* rider, size_t rider_bytes) {
+               const SortMirror* mirror) {
   const Layout L = layout((uint32_t)P);
-  // the rider, if any, in four shares: beside the histogram kernel and the first three passes
-  const size_t rider_vecs = rider ? rider_bytes / 16 : 0, share = rider_vecs / 4;
-  auto rider_share = [&](int k) {
-    return gsr::RiderFill{(uint4*)rider + (size_t)k * share, k == 3 ? rider_vecs - 3 * share : share};
-  };
   char* base = (char*)scratch;
   uint32_t* hist = (uint32_t*)base;
   uint32_t* ctl = hist + kHistWords;
@@ -516,25 +506,22 @@ int depth_sort(int P, const uint32_t* keys, const uint64_t* vals, uint64_t* sort
   const unsigned hist_wanted = ((unsigned)P + 4095u) / 4096u;
   // 512: measured against 32 .. 2048 at 1M and 6M keys (fewer blocks serialise the LDS counting, more only add flush atomics)
   const unsigned hist_blocks = hist_wanted < 512u ? hist_wanted : 512u;
-  hipLaunchKernelGGL(sort_histogram_kernel, dim3(hist_blocks + gsr::rider_blocks(rider_share(0).vecs)), dim3(kThreads), 0, st, keys,
-                     (uint32_t)P, hist, ctl, hist_blocks, rider_share(0));
+  hipLaunchKernelGGL(sort_histogram_kernel, dim3(hist_blocks), dim3(kThreads), 0, st, keys, (uint32_t)P, hist, ctl);
   const dim3 block(kThreads);
   const uint32_t spin_limit = g_spin_limit.load(std::memory_order_relaxed);
   const uint32_t static_order = L.workgroups <= resident_workgroups(items_per_thread((uint32_t)P)) ? 1u : 0u;
   const size_t per_pass = L.state_words + L.group_words;
   auto args = [&](int pass, const uint32_t* kin, const u64* vin, uint32_t* kout, u64* vout) {
     uint32_t* s = states + pass * per_pass;
-    const gsr::RiderFill fill = pass < 3 ? rider_share(pass + 1) : gsr::RiderFill{nullptr, 0};
-    return PassArgs{kin, vin, kout, vout, (u64*)sorted_vals, hist, ctl, s, s + L.state_words, (uint32_t)P, spin_limit, static_order,
-                    L.workgroups, fill};
+    return PassArgs{kin, vin, kout, vout, (u64*)sorted_vals, hist, ctl, s, s + L.state_words, (uint32_t)P, spin_limit, static_order};
   };
-  auto grid = [&](int pass) { return dim3(L.workgroups + (pass < 3 ? gsr::rider_blocks(rider_share(pass + 1).vecs) : 0u)); };
+  const dim3 grid(L.workgroups);
   auto passes = [&](auto items) {
     constexpr int I = decltype(items)::value;
-    hipLaunchKernelGGL((sort_pass_kernel<0, I>), grid(0), block, 0, st, args(0, keys, (const u64*)vals, ka, va));
-    hipLaunchKernelGGL((sort_pass_kernel<1, I>), grid(1), block, 0, st, args(1, ka, va, kb, vb));
-    hipLaunchKernelGGL((sort_pass_kernel<2, I>), grid(2), block, 0, st, args(2, kb, vb, ka, va));
-    hipLaunchKernelGGL((sort_pass_kernel<3, I>), grid(3), block, 0, st, args(3, ka, va, nullptr, nullptr));
+    hipLaunchKernelGGL((sort_pass_kernel<0, I>), grid, block, 0, st, args(0, keys, (const u64*)vals, ka, va));
+    hipLaunchKernelGGL((sort_pass_kernel<1, I>), grid, block, 0, st, args(1, ka, va, kb, vb));
+    hipLaunchKernelGGL((sort_pass_kernel<2, I>), grid, block, 0, st, args(2, kb, vb, ka, va));
+    hipLaunchKernelGGL((sort_pass_kernel<3, I>), grid, block, 0, st, args(3, ka, va, nullptr, nullptr));
   };
   switch (items_per_thread((uint32_t)P)) {
     case kManyItems: passes(std::integral_constant<int, kManyItems>{}); break;
@@ -622,5 +609,5 @@ extern "C" int gsr_bin_sort_static(int P, const uint32_t* depth_keys, const uint
   GSR_REQUIRE(depth_keys && sort_vals && sorted_vals, "bin_sort_static: null pointer");
   // depth_sort clears the look-back words, tickets, histograms and the error word with a kernel of its own
   // before it uses them: whatever the previous call left in the array does not matter
-  return gsr::depth_sort(P, depth_keys, sort_vals, sorted_vals, ptr, (hipStream_t)stream, nullptr, nullptr, 0);
+  return gsr::depth_sort(P, depth_keys, sort_vals, sorted_vals, ptr, (hipStream_t)stream);
 }

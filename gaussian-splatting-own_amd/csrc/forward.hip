@@ -78,7 +78,6 @@ extern "C" int gsr_forward(const GsrForwardArgs* a, gsr_resize_fn resize, void* 
   const uint32_t* sort_error = nullptr;
   GSR_REQUIRE(a->zero_fill_bytes == 0 || (a->zero_fill && ((uintptr_t)a->zero_fill & 15) == 0 && a->zero_fill_bytes % 16 == 0),
               "forward: the zero-fill must be 16-byte aligned and a multiple of 16 bytes");
-  const size_t sort_share = P > 0 ? gsr::rider_share_of_sort(a->zero_fill_bytes) : 0;   // without a sort the list builder clears all
   if (P > 0) {
     int rc;
     if (a->raw)
@@ -108,9 +107,7 @@ extern "C" int gsr_forward(const GsrForwardArgs* a, gsr_resize_fn resize, void* 
       if (e != hipSuccess) return hip_fail("read-back of the list sizes", e);
     }
     const gsr::SortMirror mirror{w.totals, (uint32_t*)landing, (hipEvent_t)a->event};
-    // the caller's zero-fill rides on the sort's and the list builder's latency-bound kernels, a share each
-    rc = gsr::depth_sort(P, w.depth_keys, w.sort_vals, w.sorted_vals, w.sort_scratch, st, landing ? &mirror : nullptr,
-                         a->zero_fill, gsr::rider_share_of_sort(a->zero_fill_bytes));
+    rc = gsr::depth_sort(P, w.depth_keys, w.sort_vals, w.sorted_vals, w.sort_scratch, st, landing ? &mirror : nullptr);
     if (rc) return rc;
     sort_error = gsr_bin_sort_error_word(w.sort_scratch);
     if (a->debug && (rc = gsr_bin_sort_status(P, w.sort_scratch, w.sort_bytes, stream))) return rc;
@@ -139,14 +136,14 @@ extern "C" int gsr_forward(const GsrForwardArgs* a, gsr_resize_fn resize, void* 
   out->point_list = got.take<uint32_t>(list_words * 4);
   out->tile_ids_sorted = a->keep_tile_ids ? got.take<uint32_t>(list_words * 4) : nullptr;
   void* lists_scratch = got.take<char>(lists_bytes);
-  int rc = gsr::bin_lists(P, V, N, E1, E2, W, H, w.sorted_vals, out->point_list, w.ranges, out->tile_ids_sorted, sort_error,
-                          P > 0 ? w.totals : nullptr, a->status, lists_scratch, lists_bytes,
-                          a->zero_fill ? (char*)a->zero_fill + sort_share : nullptr, a->zero_fill_bytes - sort_share, st);
+  int rc = gsr_bin_lists(P, V, N, E1, E2, W, H, w.sorted_vals, out->point_list, w.ranges, out->tile_ids_sorted, sort_error,
+                         P > 0 ? w.totals : nullptr, a->status, lists_scratch, lists_bytes, stream);
   if (rc) return rc;
   if ((rc = checkpoint("bin_lists"))) return rc;
   if (a->before_blend) a->before_blend(a->hook_ctx);
-  rc = gsr_blend_fwd_timed(W, H, w.ranges, out->point_list, w.records, a->bg, a->out_color, w.final_T, w.n_contrib,
-                           a->blend_start_event, a->blend_stop_event, stream);
+  // the caller's zero-fill rides on the blend kernel, whose workgroups leave HBM almost idle
+  rc = gsr::blend_fwd(W, H, w.ranges, out->point_list, w.records, a->bg, a->out_color, w.final_T, w.n_contrib, a->zero_fill,
+                      a->zero_fill_bytes, a->blend_start_event, a->blend_stop_event, st);
   if (rc) return rc;
   return checkpoint("blend");
 }

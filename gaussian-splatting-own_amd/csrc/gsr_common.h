@@ -65,22 +65,6 @@ inline Pack make_pack(int P, int tiles_x, int tiles_y) {
 // A caller's zero-fill riding on kernels that leave most of the GPU idle (one-block prefix sums, the short
 // workgroup chains of the depth sort): the workgroups of a launch from index `first` on clear `vecs` 16-byte
 // words and leave, the others do the kernel's own work.
-struct RiderFill {
-  uint4* at;
-  size_t vecs;
-};
-
-__device__ __forceinline__ void rider_fill(const RiderFill& f, unsigned first) {
-  const size_t stride = (size_t)(gridDim.x - first) * blockDim.x;
-  for (size_t i = (size_t)(blockIdx.x - first) * blockDim.x + threadIdx.x; i < f.vecs; i += stride)
-    f.at[i] = make_uint4(0u, 0u, 0u, 0u);
-}
-
-inline unsigned rider_blocks(size_t vecs) {   // workgroups of 1024 threads: four stores per thread, at most two per CU
-  const size_t want = (vecs + 4 * 1024 - 1) / (4 * 1024);
-  return (unsigned)(want < 512 ? want : 512);
-}
-
 // Sums `blocks` partial records of four counters (partials[4 * b + k]) into totals[0..3] and copies
 // the caller's status word (null = 0) to totals[4]; defined with the binning kernels.
 int launch_totals_final(int blocks, const uint32_t* partials, const uint32_t* status, uint32_t* totals,
@@ -97,9 +81,8 @@ struct SortMirror {
   uint32_t* dst;
   hipEvent_t event;
 };
-// rider: memory to clear beside the sort's kernels (16-byte aligned, bytes a multiple of 16; null = none)
 int depth_sort(int P, const uint32_t* keys, const uint64_t* vals, uint64_t* sorted_vals, void* scratch,
-               hipStream_t stream, const SortMirror* mirror = nullptr, void* rider = nullptr, size_t rider_bytes = 0);
+               hipStream_t stream, const SortMirror* mirror = nullptr);
 // Waits for the stream, then GSR_OK or GSR_E_SORT for the sort that last used this scratch.
 int depth_sort_status(const void* scratch, hipStream_t stream);
 // Device address of the word that is non-zero after a sort that gave up (inside its scratch).
@@ -107,15 +90,10 @@ const uint32_t* depth_sort_error_word(const void* scratch);
 // Look-back steps a workgroup waits before it gives up (0 = the default); for tests of that path.
 void set_sort_spin_limit(uint32_t limit);
 
-// gsr_bin_lists with a rider: zero_fill_bytes of device memory at zero_fill (16-byte aligned, a multiple of
-// 16 bytes; 0 = none) are cleared by workgroups that run beside the list builder's one-block scan kernels.
-int bin_lists(int P, uint32_t V, uint32_t N, uint32_t E1, uint32_t E2, int W, int H, const uint64_t* sorted_vals,
-              uint32_t* point_list, uint32_t* ranges, uint32_t* tile_ids_sorted, const uint32_t* sort_error,
-              const uint32_t* totals, uint32_t* status, void* scratch, size_t scratch_bytes, void* zero_fill,
-              size_t zero_fill_bytes, hipStream_t stream);
-// How gsr_forward splits its caller's zero-fill between the depth sort (four kernels that can carry a share)
-// and the list builder (three): bytes for the sort, a multiple of 16.
-inline size_t rider_share_of_sort(size_t bytes) { return bytes / 16 * 4 / 7 * 16; }
+// gsr_blend_fwd_timed with a zero-fill: every workgroup clears an equal share of it as its last act.
+int blend_fwd(int W, int H, const uint32_t* ranges, const uint32_t* point_list, const uint32_t* records, const float* bg,
+              float* out_color, float* final_T, uint32_t* n_contrib, void* zero_fill, size_t zero_fill_bytes,
+              void* start_event, void* stop_event, hipStream_t stream);
 
 }  // namespace gsr
 

@@ -44,9 +44,10 @@ REFERENCE_LISTS = os.environ.get("GSR_SHORT_LISTS", "0") in ("", "0")
 # two streams do not hide beside each other here, the binning slows down by more than the 13 us the fill
 # takes (1M Gaussians: train step 0.905 ms without, 0.92 ms with; tools/exp_overlap.py).
 _OVERLAP = os.environ.get("GSR_OVERLAP", "0") not in ("", "0")
-# In the single call the library clears that accumulator itself, with workgroups that ride on the list
-# builder's one-block scan kernels (the GPU is idle beside those).  GSR_NO_RIDER=1 leaves the fill to the
-# backward, for measurements of the difference.
+# In the single call the library clears that accumulator itself, at the end of the blend kernel's workgroups
+# (that kernel leaves HBM almost idle), and the blend backward clears the gradient tensors of the per-Gaussian
+# backward the same way.  GSR_NO_RIDER=1 leaves both to fill kernels in the backward, for measurements of the
+# difference.
 _RIDER = os.environ.get("GSR_NO_RIDER", "0") in ("", "0")
 # The forward is ONE call into the library (gsr_forward) unless GSR_STAGED=1 or a stage timer is installed;
 # then it is the sequence of stage calls, with the same results bit for bit.
@@ -114,6 +115,7 @@ def _load():
     lib.gsr_blend_bwd.argtypes = [ci, ci, vp, vp, vp, vp, vp, vp, vp, vp, vp]
     lib.gsr_blend_fwd_timed.argtypes = [ci, ci, vp, vp, vp, vp, vp, vp, vp, vp, vp, vp]
     lib.gsr_blend_bwd_timed.argtypes = [ci, ci, vp, vp, vp, vp, vp, vp, vp, vp, vp, vp, vp]
+    lib.gsr_blend_bwd_fill.argtypes = [ci, ci, vp, vp, vp, vp, vp, vp, vp, vp, vp, C.c_size_t, vp, vp, vp]
     lib.gsr_event_create.restype = vp
     lib.gsr_event_create_untimed.restype = vp
     lib.gsr_event_destroy.argtypes, lib.gsr_event_destroy.restype = [vp], None
@@ -391,6 +393,16 @@ def _gradient_shapes(P: int, raw: bool, n_rest: int = 0, M: int = 0, colors: boo
     return shapes
 
 
+class _GradBlock:
+    """Gradient tensors carved from the forward's allocation: `views` (name -> tensor, shapes as in `shapes`) lie in
+    the `nbytes` bytes at address `at`, which the blend backward clears (`cleared`) before the per-Gaussian backward
+    may take them as zeroed."""
+    __slots__ = ("shapes", "views", "at", "nbytes", "cleared")
+
+    def __init__(self, shapes, views, at, nbytes):
+        self.shapes, self.views, self.at, self.nbytes, self.cleared = shapes, views, at, nbytes, False
+
+
 _carve_plans: dict = {}
 
 
@@ -424,6 +436,22 @@ def _carve_zero_block(P: int, shapes: dict, dev):
     block = torch.empty((total,), dtype=torch.float32, device=dev)
     views = {k: torch.as_strided(block, shape, stride, off) for k, shape, stride, off in pieces}
     return block, torch.as_strided(block, (P, GRAD_WORDS), (GRAD_WORDS, 1), 0), views
+
+
+def _backward_block(st: ForwardState, raw, shs, cov3D_precomp, dev):
+    """One allocation for the accumulator of the blend backward (st.dsplat), which the forward clears, and the
+    gradient tensors of the per-Gaussian backward (st.zeroed_grads), which the blend backward clears; the
+    per-Gaussian backward then writes only the rows of Gaussians that have gradients.  Returns the accumulator's
+    (address, bytes)."""
+    if raw is not None:
+        rest = raw["features_rest"]
+        shapes = _gradient_shapes(st.P, True, n_rest=0 if rest is None else rest.shape[1])
+    else:
+        shapes = _gradient_shapes(st.P, False, M=st.M, colors=shs is None, cov3D=cov3D_precomp is not None)
+    block, st.dsplat, views = _carve_zero_block(st.P, shapes, dev)
+    at, nbytes = block.data_ptr(), st.dsplat.numel() * 4
+    st.zeroed_grads = _GradBlock(shapes, views, at + nbytes, block.numel() * 4 - nbytes)
+    return at, nbytes
 
 
 def _thread_callbacks():
@@ -483,18 +511,7 @@ def _forward_single_call(s, st, dev, means3D, opacities, shs, colors_precomp, sc
     a.P, a.D, a.W, a.H = P, st.D, W, H
     p = lambda t: None if t is None else t.data_ptr()
     if prepare_backward and hooks is None and P > 0 and _RIDER:
-        # The accumulator of the blend backward and the gradient tensors of the per-Gaussian backward are cleared
-        # by the library beside its one-block scan kernels; the backward then writes only the rows of Gaussians
-        # that have gradients.
-        if raw is not None:
-            rest = raw["features_rest"]
-            shapes = _gradient_shapes(P, True, n_rest=0 if rest is None else rest.shape[1])
-        else:
-            shapes = _gradient_shapes(P, False, M=st.M, colors=shs is None, cov3D=cov3D_precomp is not None)
-        block, st.dsplat, views = _carve_zero_block(P, shapes, dev)
-        st.zeroed_grads = (shapes, views)
-        a.zero_fill, a.zero_fill_bytes = block.data_ptr(), block.numel() * 4
-        del block
+        a.zero_fill, a.zero_fill_bytes = _backward_block(st, raw, shs, cov3D_precomp, dev)
     if raw is not None:
         r = {k: _f32(v, k) for k, v in raw.items()}
         n_rest = 0 if r["features_rest"] is None else r["features_rest"].shape[1]
@@ -643,6 +660,9 @@ def rasterize_forward(s: GaussianRasterizationSettings, means3D, opacities, shs=
                 st.dsplat.zero_()
                 cleared = torch.cuda.Event()
                 cleared.record(side)
+        elif prepare_backward and _RIDER:
+            _backward_block(st, raw, shs, cov3D_precomp, dev)
+            st.dsplat.zero_()                                 # the single call has the blend kernel do this
 
         # The list sizes go to the host (the pipeline's one read-back) while the GPU sorts by depth:
         # the copy is queued before the sort and the host waits for the copy alone.
@@ -674,7 +694,7 @@ def rasterize_forward(s: GaussianRasterizationSettings, means3D, opacities, shs=
     guards = (sort_error, _ptr(totals), _ptr(status)) if P > 0 else (None, None, None)
     _run("bin_lists", _lib.gsr_bin_lists, P, V, N, E1, E2, W, H, _ptr(st.sorted_vals), _ptr(st.point_list),
          _ptr(st.ranges), _ptr(st.tile_ids_sorted), *guards, _ptr(scratch), nb, stream)
-    if st.dsplat is not None:
+    if P > 0 and prepare_backward and _OVERLAP:
         torch.cuda.current_stream(dev).wait_event(cleared)
     _run_blend("blend_fwd", _lib.gsr_blend_fwd, _lib.gsr_blend_fwd_timed, W, H, _ptr(st.ranges), _ptr(st.point_list),
                _ptr(st.records), _ptr(st.bg), _ptr(st.color), _ptr(st.final_T), _ptr(st.n_contrib))
@@ -691,9 +711,14 @@ def blend_backward(st: ForwardState, grad_color: torch.Tensor) -> torch.Tensor:
     if dsplat is None:
         dsplat = torch.zeros((st.P, GRAD_WORDS), dtype=torch.float32, device=grad_color.device)
     if st.P > 0 and st.num_rendered > 0:
-        _run_blend("blend_bwd", _lib.gsr_blend_bwd, _lib.gsr_blend_bwd_timed, st.W, st.H, _ptr(st.ranges),
-                   _ptr(st.point_list), _ptr(st.records), _ptr(st.bg), _ptr(st.final_T), _ptr(st.n_contrib),
-                   _ptr(grad_color), _ptr(dsplat))
+        # the gradient tensors that came with the accumulator are cleared by this kernel's workgroups
+        held = st.zeroed_grads
+        fill = (None, 0) if held is None or held.cleared else (C.c_void_p(held.at), held.nbytes)
+        args = (st.W, st.H, _ptr(st.ranges), _ptr(st.point_list), _ptr(st.records), _ptr(st.bg), _ptr(st.final_T),
+                _ptr(st.n_contrib), _ptr(grad_color), _ptr(dsplat), *fill)
+        _run_blend("blend_bwd", lambda *a: _lib.gsr_blend_bwd_fill(*a[:-1], None, None, a[-1]), _lib.gsr_blend_bwd_fill, *args)
+        if held is not None:
+            held.cleared = True
     return dsplat
 
 
@@ -738,9 +763,9 @@ def _take_zeroed_grads(st: ForwardState, shapes: dict):
     """The gradient tensors the forward had cleared, if they fit this backward (same tensors, same shapes) and
     have not been handed out yet; good for one backward, like the accumulator."""
     held, st.zeroed_grads = st.zeroed_grads, None
-    if held is None or held[0] != shapes:
+    if held is None or not held.cleared or held.shapes != shapes:
         return None
-    return held[1]
+    return held.views
 
 
 def rasterize_backward_raw(s: GaussianRasterizationSettings, st: ForwardState, grad_color, xyz, raw: dict,

@@ -46,7 +46,7 @@
 extern "C" {
 #endif
 
-#define GSR_VERSION 4
+#define GSR_VERSION 5
 
 #define GSR_OK 0
 #define GSR_E_INVALID (-1)   /* bad argument (null pointer, negative size, unsupported M/D) */
@@ -267,10 +267,10 @@ int gsr_blend_fwd(int W, int H, const uint32_t* ranges, const uint32_t* point_li
  * depth sort and to make `stream` wait for it before the blend.
  * zero_fill, zero_fill_bytes (optional; 16-byte aligned, a multiple of 16 bytes):
  * device memory of the caller's that is zero when the call's work on `stream`
- * is done, e.g. the (P,16) accumulator of gsr_blend_bwd.  It is cleared by
- * workgroups that run beside the list builder's one-block prefix-sum kernels,
- * which otherwise leave the rest of the GPU idle: the fill costs no time of
- * its own.
+ * is done, e.g. the (P,16) accumulator of gsr_blend_bwd.  Every workgroup of
+ * the blend kernel clears an equal share of it as its last act: that kernel
+ * leaves HBM almost idle, so 64 MB cost it 3 us where a fill kernel of its own
+ * takes 10.
  * If totals[4] shows that an earlier call on the same status word built no
  * lists, the call stops before its own lists with GSR_E_EARLIER
  * (out->carried_status holds the bits; clearing the word is the caller's). */
@@ -287,7 +287,7 @@ typedef struct GsrForwardArgs {
   uint32_t* h_totals; void* event; uint32_t* status;
   void (*after_preprocess)(void* ctx); void (*before_blend)(void* ctx); void* hook_ctx;
   void* blend_start_event; void* blend_stop_event;   /* optional, as for gsr_blend_fwd_timed */
-  void* zero_fill; size_t zero_fill_bytes;           /* optional rider, see above */
+  void* zero_fill; size_t zero_fill_bytes;           /* optional, see above */
 } GsrForwardArgs;
 typedef struct GsrForwardOut {
   uint32_t N, V, E1, E2, carried_status;
@@ -313,6 +313,20 @@ int gsr_blend_bwd(int W, int H, const uint32_t* ranges, const uint32_t* point_li
                   const uint32_t* records, const float* bg, const float* final_T,
                   const uint32_t* n_contrib, const float* dL_dpix, float* dL_dsplat,
                   void* stream);
+/* The same with a zero-fill like gsr_forward's (zero_fill_bytes of device memory at
+ * zero_fill, 16-byte aligned, a multiple of 16 bytes, none of it inside dL_dsplat;
+ * 0 = none): zero when the call's work on `stream` is done, cleared by the blend
+ * kernel's workgroups as their last act.  Meant for the outputs of
+ * gsr_preprocess_bwd with outputs_zeroed (248 MB at a million Gaussians cost this
+ * kernel 9 us; a fill kernel of their own takes 36).  start_event / stop_event as
+ * for gsr_blend_bwd_timed, both may be NULL.  The reference has no counterpart: the
+ * backward of its rasterizer submodule (diff-gaussian-rasterization, RasterizeGaussiansBackwardCUDA)
+ * allocates its gradient tensors zeroed. */
+int gsr_blend_bwd_fill(int W, int H, const uint32_t* ranges, const uint32_t* point_list,
+                       const uint32_t* records, const float* bg, const float* final_T,
+                       const uint32_t* n_contrib, const float* dL_dpix, float* dL_dsplat,
+                       void* zero_fill, size_t zero_fill_bytes, void* start_event, void* stop_event,
+                       void* stream);
 
 /* ---- Kernel-exact timing of the two blend kernels ----------------------------
  * The same calls with a pair of events (hipEvent_t passed as void*, from
@@ -342,7 +356,7 @@ int gsr_blend_bwd_timed(int W, int H, const uint32_t* ranges, const uint32_t* po
  * dL_dshs (P,M,3) or dL_dcolors (P,3), dL_dscales (P,3) + dL_drotations (P,4)
  * or dL_dcov3D (P,6).  Pointers of the unused alternatives are NULL.
  * outputs_zeroed != 0: the caller promises that every output is zero already
- * (e.g. cleared by gsr_forward's zero_fill rider).  Every gradient is linear in
+ * (e.g. cleared by gsr_blend_bwd_fill).  Every gradient is linear in
  * the Gaussian's row of dL_dsplat, so a Gaussian with an all-zero row (culled, or
  * never blended because it is hidden: most Gaussians of a dense scene) has zero
  * gradients; the kernel then writes only the rows of the others and skips the

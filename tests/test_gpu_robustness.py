@@ -238,10 +238,12 @@ def test_single_call_forward_equals_the_stage_calls(raw):
     assert st.num_rendered == 0 and torch.equal(st.color, bg.cuda()[:, None, None].expand_as(st.color))
 
 
-def test_the_forward_clears_the_backward_accumulator_beside_its_scans():
-    """prepare_backward through the single call: the (P,16) accumulator of the blend backward is handed to
-    gsr_forward as its zero-fill rider.  Whatever the block held before (the allocator's cache is poisoned
-    first), it is all zeros when the forward's work is done; also when no list is built (everything culled)."""
+def test_the_blend_kernels_clear_what_the_backward_wants_zeroed():
+    """prepare_backward through the single call: the (P,16) accumulator of the blend backward is gsr_forward's
+    zero-fill, and the gradient tensors carved from the same allocation are the zero-fill of gsr_blend_bwd_fill.
+    Whatever the block held before (the allocator's cache is poisoned first), the accumulator is all zeros when
+    the forward's work is done and the gradient tensors are when the blend backward's is; also when no list is
+    built (everything culled): then no blend backward runs and the per-Gaussian backward writes every row."""
     import diff_gaussian_rasterization as dgr
     cloud, cam, bg, _ = make_scene(30_001, 500, 300, sh_degree=0, seed=21, coeffs=1)
     s = _gpu_settings(cam, bg, 0, 1.0)
@@ -249,7 +251,7 @@ def test_the_forward_clears_the_backward_accumulator_beside_its_scans():
     behind = c.xyz.clone()
     behind[:, 2] += 100.0
     for xyz, rendered in ((c.xyz, True), (behind, False)):
-        poison = torch.full((c.xyz.shape[0], 16), float("nan"), device="cuda")
+        poison = torch.full((c.xyz.shape[0], 48), float("nan"), device="cuda")
         del poison                                     # back to the caching allocator, still NaN
         st = dgr.rasterize_forward(s, xyz, c.opacity, shs=c.features, scales=c.scaling, rotations=c.rotation,
                                    single_call=True, prepare_backward=True)
@@ -257,6 +259,50 @@ def test_the_forward_clears_the_backward_accumulator_beside_its_scans():
         assert (st.num_rendered > 0) == rendered
         assert st.dsplat is not None and st.dsplat.shape == (c.xyz.shape[0], 16)
         assert int(st.dsplat.view(torch.int32).abs().max()) == 0
+        held = st.zeroed_grads
+        assert held is not None and not held.cleared
+        dsplat = dgr.blend_backward(st, torch.zeros_like(st.color))
+        torch.cuda.synchronize()
+        assert held.cleared == rendered
+        if rendered:
+            for name, v in held.views.items():
+                assert int(v.view(torch.int32).abs().max()) == 0, name
+        g = dgr.rasterize_backward(s, st, torch.zeros_like(st.color), xyz, shs=c.features, scales=c.scaling,
+                                   rotations=c.rotation, dsplat=dsplat)
+        for name, v in g.items():
+            if v is not None:
+                assert int(v.view(torch.int32).abs().max()) == 0, name
+
+
+def test_blend_backward_with_a_zero_fill_through_the_c_abi():
+    """gsr_blend_bwd_fill against gsr_blend_bwd: the same sums (up to the order of the atomic additions), and
+    the fill is all zeros, for sizes that do not divide by the number of workgroups and for one smaller than it."""
+    import ctypes as C
+    import diff_gaussian_rasterization as dgr
+    cloud, cam, bg, _ = make_scene(20_000, 333, 222, sh_degree=0, seed=5, coeffs=1)
+    s = _gpu_settings(cam, bg, 0, 1.0)
+    c = cloud.to("cuda")
+    st = dgr.rasterize_forward(s, c.xyz, c.opacity, shs=c.features, scales=c.scaling, rotations=c.rotation)
+    d = torch.rand_like(st.color)
+    lib, p = dgr._lib, lambda t: C.c_void_p(t.data_ptr())
+    stream = C.c_void_p(torch.cuda.current_stream().cuda_stream)
+    common = (st.W, st.H, p(st.ranges), p(st.point_list), p(st.records), p(st.bg), p(st.final_T), p(st.n_contrib), p(d))
+    plain = torch.zeros((st.P, 16), device="cuda")
+    assert lib.gsr_blend_bwd(*common, p(plain), stream) == 0
+    for nbytes in (16, 16 * 77, 16 * 1_000_003):
+        guard = 64
+        buf = torch.full((nbytes // 4 + 2 * guard,), float("nan"), device="cuda")
+        got = torch.zeros((st.P, 16), device="cuda")
+        rc = lib.gsr_blend_bwd_fill(*common, p(got), C.c_void_p(buf.data_ptr() + 4 * guard), nbytes, None, None, stream)
+        assert rc == 0, lib.gsr_last_error().decode()
+        torch.cuda.synchronize()
+        assert int(buf[guard:-guard].view(torch.int32).abs().max()) == 0
+        assert bool(torch.isnan(buf[:guard]).all()) and bool(torch.isnan(buf[-guard:]).all())   # nothing beyond it
+        assert float((got - plain).abs().max()) <= 1e-5 * float(plain.abs().max())   # atomic additions in another order
+    # misaligned or ragged fills are refused
+    buf = torch.zeros((64,), device="cuda")
+    assert lib.gsr_blend_bwd_fill(*common, p(plain), C.c_void_p(buf.data_ptr() + 4), 16, None, None, stream) != 0
+    assert lib.gsr_blend_bwd_fill(*common, p(plain), p(buf), 24, None, None, stream) != 0
 
 
 def test_two_host_threads_on_their_own_streams():
