@@ -347,6 +347,10 @@ def main():
                          "traffic": lim.get("measured_hbm_bytes"),
                          "traffic_unit": "bytes/launch (rocprofv3 FETCH_SIZE x2 + WRITE_SIZE)",
                          "kernel_ms": round(dom_ms, 4),
+                         "kernel_also_clears_bytes": 248 * P,
+                         "kernel_also_clears": "the gradient tensors of preprocess_bwd (62 floats per Gaussian), a share "
+                                               "per workgroup after its own work (gsr_blend_bwd_fill); not counted in "
+                                               "the algorithmic bytes, included in kernel_ms",
                          "kernel_ms_from": "HIP events stamped by the kernel's launch (its own start and end), mean over "
                                            + (f"the {args.steps} timed steps" if args.events_in_timed_steps else
                                               f"{args.steps} steps run right after the timed ones (inside them such "
