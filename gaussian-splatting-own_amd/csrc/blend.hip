@@ -144,9 +144,13 @@ __device__ __forceinline__ void fill_my_share(const ShareFill& f) {
   for (size_t i = first + threadIdx.x; i < end; i += 256) f.at[i] = make_uint4(0u, 0u, 0u, 0u);   // workgroups of 256
 }
 
-inline ShareFill share_fill(void* zero_fill, size_t bytes, dim3 grid) {
+inline size_t fill_share(size_t bytes, dim3 grid) {
   const size_t vecs = bytes / 16, groups = (size_t)grid.x * grid.y;
-  return ShareFill{(uint4*)zero_fill, vecs, (uint32_t)((vecs + groups - 1) / groups)};
+  return (vecs + groups - 1) / groups;
+}
+
+inline ShareFill share_fill(void* zero_fill, size_t bytes, dim3 grid) {
+  return ShareFill{(uint4*)zero_fill, bytes / 16, (uint32_t)fill_share(bytes, grid)};
 }
 
 __global__ void __launch_bounds__(256) blend_fwd_kernel(int W, int H, const uint2* __restrict__ ranges,
@@ -445,6 +449,8 @@ int launch_blend_fwd(int W, int H, const uint32_t* ranges, const uint32_t* point
               "blend_fwd: zero_fill must be 16-byte aligned and a multiple of 16 bytes");
   GSR_REQUIRE(ranges && bg && out_color && final_T && n_contrib, "blend_fwd: null pointer");
   dim3 grid(gsr::div_up(W, GSR_TILE_X), gsr::div_up(H, GSR_TILE_Y)), block(256);
+  GSR_REQUIRE(fill_share(zero_fill_bytes, grid) <= 0xFFFFFFFFull, "blend: zero_fill of %zu bytes is too large for %u workgroups",
+              zero_fill_bytes, grid.x * grid.y);
   const ShareFill fill = share_fill(zero_fill, zero_fill_bytes, grid);
   if (start || stop)
     hipExtLaunchKernelGGL(blend_fwd_kernel, grid, block, 0, (hipStream_t)stream, start, stop, 0, W, H, (const uint2*)ranges,
@@ -465,6 +471,8 @@ int launch_blend_bwd(int W, int H, const uint32_t* ranges, const uint32_t* point
   GSR_REQUIRE(ranges && bg && final_T && n_contrib && dL_dpix && dL_dsplat, "blend_bwd: null pointer");
   GSR_REQUIRE(((uintptr_t)dL_dsplat & 63) == 0, "blend_bwd: dL_dsplat must be 64-byte aligned");
   dim3 grid(gsr::div_up(W, GSR_TILE_X), gsr::div_up(H, GSR_TILE_Y)), block(256);
+  GSR_REQUIRE(fill_share(zero_fill_bytes, grid) <= 0xFFFFFFFFull, "blend: zero_fill of %zu bytes is too large for %u workgroups",
+              zero_fill_bytes, grid.x * grid.y);
   const ShareFill fill = share_fill(zero_fill, zero_fill_bytes, grid);
   if (start || stop)
     hipExtLaunchKernelGGL(blend_bwd_kernel, grid, block, 0, (hipStream_t)stream, start, stop, 0, W, H, (const uint2*)ranges,

@@ -46,9 +46,9 @@ REFERENCE_LISTS = os.environ.get("GSR_SHORT_LISTS", "0") in ("", "0")
 _OVERLAP = os.environ.get("GSR_OVERLAP", "0") not in ("", "0")
 # In the single call the library clears that accumulator itself, at the end of the blend kernel's workgroups
 # (that kernel leaves HBM almost idle), and the blend backward clears the gradient tensors of the per-Gaussian
-# backward the same way.  GSR_NO_RIDER=1 leaves both to fill kernels in the backward, for measurements of the
-# difference.
-_RIDER = os.environ.get("GSR_NO_RIDER", "0") in ("", "0")
+# backward the same way.  GSR_SEPARATE_FILLS=1, for measurements of the difference: the accumulator is cleared by
+# a fill kernel in the backward and the per-Gaussian backward writes every row of its outputs.
+_CARRIED_FILLS = os.environ.get("GSR_SEPARATE_FILLS", "0") in ("", "0")
 # The forward is ONE call into the library (gsr_forward) unless GSR_STAGED=1 or a stage timer is installed;
 # then it is the sequence of stage calls, with the same results bit for bit.
 SINGLE_CALL = os.environ.get("GSR_STAGED", "0") in ("", "0")
@@ -510,7 +510,7 @@ def _forward_single_call(s, st, dev, means3D, opacities, shs, colors_precomp, sc
     a = _ForwardArgs()
     a.P, a.D, a.W, a.H = P, st.D, W, H
     p = lambda t: None if t is None else t.data_ptr()
-    if prepare_backward and hooks is None and P > 0 and _RIDER:
+    if prepare_backward and hooks is None and P > 0 and _CARRIED_FILLS:
         a.zero_fill, a.zero_fill_bytes = _backward_block(st, raw, shs, cov3D_precomp, dev)
     if raw is not None:
         r = {k: _f32(v, k) for k, v in raw.items()}
@@ -660,7 +660,7 @@ def rasterize_forward(s: GaussianRasterizationSettings, means3D, opacities, shs=
                 st.dsplat.zero_()
                 cleared = torch.cuda.Event()
                 cleared.record(side)
-        elif prepare_backward and _RIDER:
+        elif prepare_backward and _CARRIED_FILLS:
             _backward_block(st, raw, shs, cov3D_precomp, dev)
             st.dsplat.zero_()                                 # the single call has the blend kernel do this
 
