@@ -311,7 +311,7 @@ __global__ void __launch_bounds__(256) blend_bwd_kernel(int W, int H, const uint
                                                         const uint32_t* __restrict__ n_contrib,
                                                         const float* __restrict__ dL_dpix,
                                                         float* __restrict__ dL_dsplat,
-                                                        ShareFill fill) {
+                                                        uint8_t* __restrict__ touched, ShareFill fill) {
   __shared__ StagedBack s_splat[kBatch];
   __shared__ unsigned long long s_mask[4][4];
   __shared__ int s_last[4];
@@ -362,6 +362,8 @@ __global__ void __launch_bounds__(256) blend_bwd_kernel(int W, int H, const uint
       qm = quadrant_mask(sx, sy, __uint_as_float(r0.z), __uint_as_float(r0.w), __uint_as_float(r1.x),
                          __uint_as_float(r1.y), __uint_as_float(r1.z), __uint_as_float(r1.w), tx0, ty0);
       stage_record(&s_splat[threadIdx.x], r0, r1, r2, g);
+      // only staged splats can receive sums: the per-Gaussian backward need not look at the rows of the others
+      if (touched != nullptr && qm != 0u) touched[g] = 1;
     }
 #pragma unroll
     for (int q = 0; q < 4; q++) {
@@ -463,8 +465,8 @@ int launch_blend_fwd(int W, int H, const uint32_t* ranges, const uint32_t* point
 
 int launch_blend_bwd(int W, int H, const uint32_t* ranges, const uint32_t* point_list, const uint32_t* records,
                      const float* bg, const float* final_T, const uint32_t* n_contrib, const float* dL_dpix,
-                     float* dL_dsplat, void* zero_fill, size_t zero_fill_bytes, hipEvent_t start, hipEvent_t stop,
-                     void* stream) {
+                     float* dL_dsplat, uint8_t* touched, void* zero_fill, size_t zero_fill_bytes, hipEvent_t start,
+                     hipEvent_t stop, void* stream) {
   GSR_REQUIRE(W > 0 && H > 0, "blend_bwd: bad image size %dx%d", W, H);
   GSR_REQUIRE(zero_fill_bytes == 0 || (zero_fill && ((uintptr_t)zero_fill & 15) == 0 && zero_fill_bytes % 16 == 0),
               "blend_bwd: zero_fill must be 16-byte aligned and a multiple of 16 bytes");
@@ -476,10 +478,10 @@ int launch_blend_bwd(int W, int H, const uint32_t* ranges, const uint32_t* point
   const ShareFill fill = share_fill(zero_fill, zero_fill_bytes, grid);
   if (start || stop)
     hipExtLaunchKernelGGL(blend_bwd_kernel, grid, block, 0, (hipStream_t)stream, start, stop, 0, W, H, (const uint2*)ranges,
-                          point_list, (const uint4*)records, bg, final_T, n_contrib, dL_dpix, dL_dsplat, fill);
+                          point_list, (const uint4*)records, bg, final_T, n_contrib, dL_dpix, dL_dsplat, touched, fill);
   else
     hipLaunchKernelGGL(blend_bwd_kernel, grid, block, 0, (hipStream_t)stream, W, H, (const uint2*)ranges, point_list,
-                       (const uint4*)records, bg, final_T, n_contrib, dL_dpix, dL_dsplat, fill);
+                       (const uint4*)records, bg, final_T, n_contrib, dL_dpix, dL_dsplat, touched, fill);
   return gsr::check_launch("blend_bwd");
 }
 
@@ -495,7 +497,7 @@ extern "C" int gsr_blend_fwd(int W, int H, const uint32_t* ranges, const uint32_
 extern "C" int gsr_blend_bwd(int W, int H, const uint32_t* ranges, const uint32_t* point_list,
                              const uint32_t* records, const float* bg, const float* final_T,
                              const uint32_t* n_contrib, const float* dL_dpix, float* dL_dsplat, void* stream) {
-  return launch_blend_bwd(W, H, ranges, point_list, records, bg, final_T, n_contrib, dL_dpix, dL_dsplat, nullptr, 0,
+  return launch_blend_bwd(W, H, ranges, point_list, records, bg, final_T, n_contrib, dL_dpix, dL_dsplat, nullptr, nullptr, 0,
                           nullptr, nullptr, stream);
 }
 
@@ -517,14 +519,15 @@ extern "C" int gsr_blend_bwd_timed(int W, int H, const uint32_t* ranges, const u
                                    const uint32_t* records, const float* bg, const float* final_T,
                                    const uint32_t* n_contrib, const float* dL_dpix, float* dL_dsplat,
                                    void* start_event, void* stop_event, void* stream) {
-  return launch_blend_bwd(W, H, ranges, point_list, records, bg, final_T, n_contrib, dL_dpix, dL_dsplat, nullptr, 0,
+  return launch_blend_bwd(W, H, ranges, point_list, records, bg, final_T, n_contrib, dL_dpix, dL_dsplat, nullptr, nullptr, 0,
                           (hipEvent_t)start_event, (hipEvent_t)stop_event, stream);
 }
 
 extern "C" int gsr_blend_bwd_fill(int W, int H, const uint32_t* ranges, const uint32_t* point_list,
                                   const uint32_t* records, const float* bg, const float* final_T,
-                                  const uint32_t* n_contrib, const float* dL_dpix, float* dL_dsplat, void* zero_fill,
-                                  size_t zero_fill_bytes, void* start_event, void* stop_event, void* stream) {
-  return launch_blend_bwd(W, H, ranges, point_list, records, bg, final_T, n_contrib, dL_dpix, dL_dsplat, zero_fill,
+                                  const uint32_t* n_contrib, const float* dL_dpix, float* dL_dsplat, uint8_t* touched,
+                                  void* zero_fill, size_t zero_fill_bytes, void* start_event, void* stop_event,
+                                  void* stream) {
+  return launch_blend_bwd(W, H, ranges, point_list, records, bg, final_T, n_contrib, dL_dpix, dL_dsplat, touched, zero_fill,
                           zero_fill_bytes, (hipEvent_t)start_event, (hipEvent_t)stop_event, stream);
 }

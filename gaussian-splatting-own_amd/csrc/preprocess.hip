@@ -414,6 +414,7 @@ __global__ void __launch_bounds__(kBlock) mark_visible_kernel(int P, const float
 
 struct BwdArgs {
   int sparse;   // the outputs are zero already: only Gaussians with gradients write
+  const uint8_t* touched;   // sparse mode, optional: 0 = the Gaussian's row of sums is all zeros (it is not read then)
   int raw, n_rest; const float* shs_rest; const float* opacity_raw; float* dL_dshs_rest;
   int P, M, W, H;
   const float* means3D; const float* scales; const float* rotations; const float* shs;
@@ -443,7 +444,7 @@ __global__ void __launch_bounds__(kBlock, 4) preprocess_bwd_kernel(BwdArgs a) {
     __shared__ int s_active[kBlock];
     __shared__ int s_waves[kBlock / 64];
     bool active = false;
-    if (i < a.P) {
+    if (i < a.P && (a.touched == nullptr || a.touched[i] != 0)) {
       const float4* row = reinterpret_cast<const float4*>(a.dL_dsplat) + (size_t)i * (GSR_GRAD_WORDS / 4);
       const float4 r0 = row[0], r1 = row[1];
       const float r2 = reinterpret_cast<const float*>(row)[8];
@@ -818,8 +819,10 @@ extern "C" int gsr_preprocess_bwd(int P, int D, int M, const float* means3D, con
                                   float tanfovy, const uint32_t* records, const float* dL_dsplat,
                                   float* dL_dmeans3D, float* dL_dmeans2D, float* dL_dopacities,
                                   float* dL_dshs, float* dL_dcolors, float* dL_dscales,
-                                  float* dL_drotations, float* dL_dcov3D, int outputs_zeroed, void* stream) {
+                                  float* dL_drotations, float* dL_dcov3D, int outputs_zeroed, const uint8_t* touched,
+                                  void* stream) {
   GSR_REQUIRE(P >= 0 && W > 0 && H > 0, "preprocess_bwd: bad sizes");
+  GSR_REQUIRE(outputs_zeroed || !touched, "preprocess_bwd: touched goes with outputs_zeroed");
   if (P == 0) return GSR_OK;
   GSR_REQUIRE(means3D && viewmatrix && projmatrix && campos && records && dL_dsplat, "preprocess_bwd: null input");
   GSR_REQUIRE(dL_dmeans3D && dL_dmeans2D && dL_dopacities, "preprocess_bwd: null output");
@@ -832,7 +835,7 @@ extern "C" int gsr_preprocess_bwd(int P, int D, int M, const float* means3D, con
               "preprocess_bwd: scales/rotations and their gradients go together");
   GSR_REQUIRE(D >= 0 && D <= GSR_MAX_SH_DEGREE, "preprocess_bwd: SH degree %d unsupported", D);
   GSR_REQUIRE(!shs || (M >= (D + 1) * (D + 1) && M <= 16), "preprocess_bwd: M=%d unsupported for degree %d", M, D);
-  BwdArgs a{outputs_zeroed ? 1 : 0, 0, 0, nullptr, nullptr, nullptr, P, M, W, H, means3D, scales, rotations, shs, cov3D_precomp, viewmatrix, projmatrix, campos,
+  BwdArgs a{outputs_zeroed ? 1 : 0, touched, 0, 0, nullptr, nullptr, nullptr, P, M, W, H, means3D, scales, rotations, shs, cov3D_precomp, viewmatrix, projmatrix, campos,
             scale_modifier, tanfovx, tanfovy, records, dL_dsplat, dL_dmeans3D, dL_dmeans2D, dL_dopacities,
             dL_dshs, dL_dcolors, dL_dscales, dL_drotations, dL_dcov3D};
   hipStream_t st = (hipStream_t)stream;
@@ -891,8 +894,10 @@ extern "C" int gsr_preprocess_bwd_raw(int P, int D, int n_rest, const float* xyz
                                       int H, float tanfovx, float tanfovy, const uint32_t* records,
                                       const float* dL_dsplat, float* dL_dxyz, float* dL_dmeans2D,
                                       float* dL_dopacity_raw, float* dL_dfeatures_dc, float* dL_dfeatures_rest,
-                                      float* dL_dscaling_raw, float* dL_drotation_raw, int outputs_zeroed, void* stream) {
+                                      float* dL_dscaling_raw, float* dL_drotation_raw, int outputs_zeroed,
+                                      const uint8_t* touched, void* stream) {
   GSR_REQUIRE(P >= 0 && W > 0 && H > 0, "preprocess_bwd_raw: bad sizes");
+  GSR_REQUIRE(outputs_zeroed || !touched, "preprocess_bwd_raw: touched goes with outputs_zeroed");
   if (P == 0) return GSR_OK;
   GSR_REQUIRE(xyz && scaling_raw && rotation_raw && opacity_raw && features_dc && viewmatrix && projmatrix && campos &&
                   records && dL_dsplat, "preprocess_bwd_raw: null input");
@@ -902,7 +907,7 @@ extern "C" int gsr_preprocess_bwd_raw(int P, int D, int n_rest, const float* xyz
   GSR_REQUIRE(n_rest >= (D + 1) * (D + 1) - 1 && n_rest <= 15 && (n_rest == 0 || (features_rest && dL_dfeatures_rest)),
               "preprocess_bwd_raw: n_rest=%d does not hold degree %d", n_rest, D);
   const bool split = n_rest > 0;
-  BwdArgs a{outputs_zeroed ? 1 : 0, 1, n_rest, split ? features_rest : nullptr, opacity_raw, split ? dL_dfeatures_rest : nullptr,
+  BwdArgs a{outputs_zeroed ? 1 : 0, touched, 1, n_rest, split ? features_rest : nullptr, opacity_raw, split ? dL_dfeatures_rest : nullptr,
             P, 1 + n_rest, W, H, xyz, scaling_raw, rotation_raw, features_dc, nullptr, viewmatrix, projmatrix, campos,
             scale_modifier, tanfovx, tanfovy, records, dL_dsplat, dL_dxyz, dL_dmeans2D, dL_dopacity_raw,
             dL_dfeatures_dc, nullptr, dL_dscaling_raw, dL_drotation_raw, nullptr};

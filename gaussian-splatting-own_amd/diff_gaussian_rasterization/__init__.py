@@ -115,20 +115,20 @@ def _load():
     lib.gsr_blend_bwd.argtypes = [ci, ci, vp, vp, vp, vp, vp, vp, vp, vp, vp]
     lib.gsr_blend_fwd_timed.argtypes = [ci, ci, vp, vp, vp, vp, vp, vp, vp, vp, vp, vp]
     lib.gsr_blend_bwd_timed.argtypes = [ci, ci, vp, vp, vp, vp, vp, vp, vp, vp, vp, vp, vp]
-    lib.gsr_blend_bwd_fill.argtypes = [ci, ci, vp, vp, vp, vp, vp, vp, vp, vp, vp, C.c_size_t, vp, vp, vp]
+    lib.gsr_blend_bwd_fill.argtypes = [ci, ci, vp, vp, vp, vp, vp, vp, vp, vp, vp, vp, C.c_size_t, vp, vp, vp]
     lib.gsr_event_create.restype = vp
     lib.gsr_event_create_untimed.restype = vp
     lib.gsr_event_destroy.argtypes, lib.gsr_event_destroy.restype = [vp], None
     lib.gsr_event_elapsed_ms.argtypes = [vp, vp, C.POINTER(C.c_float)]
     lib.gsr_preprocess_bwd.argtypes = [ci, ci, ci, vp, vp, cf, vp, vp, vp, vp, vp, vp, ci, ci, cf, cf, vp, vp,
-                                       vp, vp, vp, vp, vp, vp, vp, vp, ci, vp]
+                                       vp, vp, vp, vp, vp, vp, vp, vp, ci, vp, vp]
     lib.gsr_preprocess_fwd_raw.argtypes = [ci, ci, ci, vp, vp, cf, vp, vp, vp, vp, vp, vp, vp, ci, ci, cf, cf, ci,
                                            vp, vp, vp, vp, vp, vp, vp, vp, vp, vp]
     lib.gsr_forward_workspace_bytes.restype = C.c_size_t
     lib.gsr_forward_workspace_bytes.argtypes = [ci, ci, ci]
     lib.gsr_forward.argtypes = [C.POINTER(_ForwardArgs), _RESIZE_FN, vp, C.POINTER(_ForwardOut), vp]
     lib.gsr_preprocess_bwd_raw.argtypes = [ci, ci, ci, vp, vp, cf, vp, vp, vp, vp, vp, vp, vp, ci, ci, cf, cf,
-                                           vp, vp, vp, vp, vp, vp, vp, vp, vp, ci, vp]
+                                           vp, vp, vp, vp, vp, vp, vp, vp, vp, ci, vp, vp]
     return lib
 
 
@@ -396,11 +396,13 @@ def _gradient_shapes(P: int, raw: bool, n_rest: int = 0, M: int = 0, colors: boo
 class _GradBlock:
     """Gradient tensors carved from the forward's allocation: `views` (name -> tensor, shapes as in `shapes`) lie in
     the `nbytes` bytes at address `at`, which the blend backward clears (`cleared`) before the per-Gaussian backward
-    may take them as zeroed."""
-    __slots__ = ("shapes", "views", "at", "nbytes", "cleared")
+    may take them as zeroed.  `touched` (P bytes, cleared by the forward): the blend backward marks the Gaussians
+    it may have sums for, the per-Gaussian backward reads the rows of those only."""
+    __slots__ = ("shapes", "views", "touched", "at", "nbytes", "cleared")
 
-    def __init__(self, shapes, views, at, nbytes):
-        self.shapes, self.views, self.at, self.nbytes, self.cleared = shapes, views, at, nbytes, False
+    def __init__(self, shapes, views, touched, at, nbytes):
+        self.shapes, self.views, self.touched, self.at, self.nbytes = shapes, views, touched, at, nbytes
+        self.cleared = False
 
 
 _carve_plans: dict = {}
@@ -408,8 +410,9 @@ _carve_plans: dict = {}
 
 def _carve_zero_block(P: int, shapes: dict, dev):
     """One allocation for everything the backward wants zeroed before it starts: the (P,16) accumulator of the
-    blend backward and the gradient tensors of the per-Gaussian backward (which then writes only the rows
-    of Gaussians that have gradients).  Returns (block, accumulator, {name: tensor}); the pieces start on
+    blend backward, the flags of the Gaussians it touches, and the gradient tensors of the per-Gaussian backward
+    (which then writes only the rows of Gaussians that have gradients).  Returns (block, accumulator, flags,
+    {name: tensor}); the pieces start on
     256-byte boundaries.  One as_strided per piece, from a plan kept per (P, shapes): this runs every step,
     and at a hundred thousand Gaussians the step is short enough for a dozen extra tensor operations to show."""
     key = (P, tuple(shapes.items()))
@@ -424,23 +427,25 @@ def _carve_zero_block(P: int, shapes: dict, dev):
                 out.append(run)
                 run *= d
             return tuple(reversed(out))
-        at = pad(P * GRAD_WORDS)
+        flags_at = pad(P * GRAD_WORDS)          # P bytes of "touched" flags behind the accumulator
+        at = flags_at + pad((P + 3) // 4)
         pieces = []
         for k, v in shapes.items():
             pieces.append((k, tuple(v), strides(v), at))
             at += pad(int(torch.Size(v).numel()))
         if len(_carve_plans) > 64:
             _carve_plans.clear()
-        plan = _carve_plans[key] = (at, pieces)
-    total, pieces = plan
+        plan = _carve_plans[key] = (at, pieces, flags_at)
+    total, pieces, flags_at = plan
     block = torch.empty((total,), dtype=torch.float32, device=dev)
     views = {k: torch.as_strided(block, shape, stride, off) for k, shape, stride, off in pieces}
-    return block, torch.as_strided(block, (P, GRAD_WORDS), (GRAD_WORDS, 1), 0), views
+    touched = block[flags_at:flags_at + (P + 3) // 4].view(torch.uint8)
+    return block, torch.as_strided(block, (P, GRAD_WORDS), (GRAD_WORDS, 1), 0), touched, views
 
 
 def _backward_block(st: ForwardState, raw, shs, cov3D_precomp, dev):
-    """One allocation for the accumulator of the blend backward (st.dsplat), which the forward clears, and the
-    gradient tensors of the per-Gaussian backward (st.zeroed_grads), which the blend backward clears; the
+    """One allocation for the accumulator of the blend backward (st.dsplat) and the flags of the Gaussians it touches, which
+    the forward clears, and the gradient tensors of the per-Gaussian backward (st.zeroed_grads), which the blend backward clears; the
     per-Gaussian backward then writes only the rows of Gaussians that have gradients.  Returns the accumulator's
     (address, bytes)."""
     if raw is not None:
@@ -448,9 +453,10 @@ def _backward_block(st: ForwardState, raw, shs, cov3D_precomp, dev):
         shapes = _gradient_shapes(st.P, True, n_rest=0 if rest is None else rest.shape[1])
     else:
         shapes = _gradient_shapes(st.P, False, M=st.M, colors=shs is None, cov3D=cov3D_precomp is not None)
-    block, st.dsplat, views = _carve_zero_block(st.P, shapes, dev)
-    at, nbytes = block.data_ptr(), st.dsplat.numel() * 4
-    st.zeroed_grads = _GradBlock(shapes, views, at + nbytes, block.numel() * 4 - nbytes)
+    block, st.dsplat, touched, views = _carve_zero_block(st.P, shapes, dev)
+    at = block.data_ptr()
+    nbytes = next(iter(views.values())).data_ptr() - at          # the accumulator and the flags
+    st.zeroed_grads = _GradBlock(shapes, views, touched, at + nbytes, block.numel() * 4 - nbytes)
     return at, nbytes
 
 
@@ -663,6 +669,7 @@ def rasterize_forward(s: GaussianRasterizationSettings, means3D, opacities, shs=
         elif prepare_backward and _CARRIED_FILLS:
             _backward_block(st, raw, shs, cov3D_precomp, dev)
             st.dsplat.zero_()                                 # the single call has the blend kernel do this
+            st.zeroed_grads.touched.zero_()
 
         # The list sizes go to the host (the pipeline's one read-back) while the GPU sorts by depth:
         # the copy is queued before the sort and the host waits for the copy alone.
@@ -713,7 +720,7 @@ def blend_backward(st: ForwardState, grad_color: torch.Tensor) -> torch.Tensor:
     if st.P > 0 and st.num_rendered > 0:
         # the gradient tensors that came with the accumulator are cleared by this kernel's workgroups
         held = st.zeroed_grads
-        fill = (None, 0) if held is None or held.cleared else (C.c_void_p(held.at), held.nbytes)
+        fill = (None, None, 0) if held is None or held.cleared else (_ptr(held.touched), C.c_void_p(held.at), held.nbytes)
         args = (st.W, st.H, _ptr(st.ranges), _ptr(st.point_list), _ptr(st.records), _ptr(st.bg), _ptr(st.final_T),
                 _ptr(st.n_contrib), _ptr(grad_color), _ptr(dsplat), *fill)
         _run_blend("blend_bwd", lambda *a: _lib.gsr_blend_bwd_fill(*a[:-1], None, None, a[-1]), _lib.gsr_blend_bwd_fill, *args)
@@ -748,14 +755,14 @@ def rasterize_backward(s: GaussianRasterizationSettings, st: ForwardState, grad_
         dsplat = blend_backward(st, grad_color)
     shapes = _gradient_shapes(P, False, M=st.M, colors=shs is None, cov3D=cov3D_precomp is not None)
     g = dict(shs=None, colors_precomp=None, scales=None, rotations=None, cov3D_precomp=None)
-    views = _take_zeroed_grads(st, shapes)
-    g.update(views if views is not None else {k: torch.empty(v, dtype=torch.float32, device=dev) for k, v in shapes.items()})
+    held = _take_zeroed_grads(st, shapes)
+    g.update(held.views if held is not None else {k: torch.empty(v, dtype=torch.float32, device=dev) for k, v in shapes.items()})
     if P > 0:
         _run("preprocess_bwd", _lib.gsr_preprocess_bwd, P, st.D, st.M, _ptr(means3D), _ptr(scales), float(s.scale_modifier), _ptr(rotations), _ptr(shs),
             _ptr(cov3D_precomp), _ptr(st.view), _ptr(st.proj), _ptr(st.campos), st.W, st.H, float(s.tanfovx),
             float(s.tanfovy), _ptr(st.records), _ptr(dsplat), _ptr(g["means3D"]), _ptr(g["means2D"]),
             _ptr(g["opacities"]), _ptr(g["shs"]), _ptr(g["colors_precomp"]), _ptr(g["scales"]), _ptr(g["rotations"]),
-            _ptr(g["cov3D_precomp"]), int(views is not None), _stream())
+            _ptr(g["cov3D_precomp"]), int(held is not None), None if held is None else _ptr(held.touched), _stream())
     return g
 
 
@@ -765,7 +772,7 @@ def _take_zeroed_grads(st: ForwardState, shapes: dict):
     held, st.zeroed_grads = st.zeroed_grads, None
     if held is None or not held.cleared or held.shapes != shapes:
         return None
-    return held.views
+    return held
 
 
 def rasterize_backward_raw(s: GaussianRasterizationSettings, st: ForwardState, grad_color, xyz, raw: dict,
@@ -779,16 +786,16 @@ def rasterize_backward_raw(s: GaussianRasterizationSettings, st: ForwardState, g
         dsplat = blend_backward(st, grad_color)
     n_rest = 0 if r["features_rest"] is None else r["features_rest"].shape[1]
     shapes = _gradient_shapes(P, True, n_rest=n_rest)
-    views = _take_zeroed_grads(st, shapes)
+    held = _take_zeroed_grads(st, shapes)
     g = dict(features_rest=None)
-    g.update(views if views is not None else {k: torch.empty(v, dtype=torch.float32, device=dev) for k, v in shapes.items()})
+    g.update(held.views if held is not None else {k: torch.empty(v, dtype=torch.float32, device=dev) for k, v in shapes.items()})
     if P > 0:
         _run("preprocess_bwd", _lib.gsr_preprocess_bwd_raw, P, st.D, n_rest, _ptr(xyz), _ptr(r["scaling"]),
              float(s.scale_modifier), _ptr(r["rotation"]), _ptr(r["opacity"]), _ptr(r["features_dc"]),
              _ptr(r["features_rest"]), _ptr(st.view), _ptr(st.proj), _ptr(st.campos), st.W, st.H, float(s.tanfovx),
              float(s.tanfovy), _ptr(st.records), _ptr(dsplat), _ptr(g["xyz"]), _ptr(g["means2D"]), _ptr(g["opacity"]),
              _ptr(g["features_dc"]), _ptr(g["features_rest"]), _ptr(g["scaling"]), _ptr(g["rotation"]),
-             int(views is not None), _stream())
+             int(held is not None), None if held is None else _ptr(held.touched), _stream())
     return g
 
 

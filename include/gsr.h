@@ -313,20 +313,24 @@ int gsr_blend_bwd(int W, int H, const uint32_t* ranges, const uint32_t* point_li
                   const uint32_t* records, const float* bg, const float* final_T,
                   const uint32_t* n_contrib, const float* dL_dpix, float* dL_dsplat,
                   void* stream);
-/* The same with a zero-fill like gsr_forward's (zero_fill_bytes of device memory at
- * zero_fill, 16-byte aligned, a multiple of 16 bytes, none of it inside dL_dsplat;
- * 0 = none): zero when the call's work on `stream` is done, cleared by the blend
- * kernel's workgroups as their last act.  Meant for the outputs of
- * gsr_preprocess_bwd with outputs_zeroed (248 MB at a million Gaussians cost this
- * kernel 9 us; a fill kernel of their own takes 36).  start_event / stop_event as
- * for gsr_blend_bwd_timed, both may be NULL.  The reference has no counterpart: the
+/* The same with two extras for gsr_preprocess_bwd's outputs_zeroed mode.
+ * touched (optional, P bytes that the caller has zeroed, e.g. as part of
+ * gsr_forward's zero_fill): set to 1 for every Gaussian whose row of dL_dsplat
+ * the call may add to; the rows of the others are still all zeros.
+ * zero_fill, zero_fill_bytes: a zero-fill like gsr_forward's (16-byte aligned, a
+ * multiple of 16 bytes, none of it inside dL_dsplat or touched; 0 = none): zero
+ * when the call's work on `stream` is done, cleared by the blend kernel's
+ * workgroups as their last act.  Meant for the outputs of gsr_preprocess_bwd
+ * (248 MB at a million Gaussians cost this kernel 9 us; a fill kernel of their
+ * own takes 36).  start_event / stop_event as for gsr_blend_bwd_timed, both may
+ * be NULL.  The reference has no counterpart: the
  * backward of its rasterizer submodule (diff-gaussian-rasterization, RasterizeGaussiansBackwardCUDA)
  * allocates its gradient tensors zeroed. */
 int gsr_blend_bwd_fill(int W, int H, const uint32_t* ranges, const uint32_t* point_list,
                        const uint32_t* records, const float* bg, const float* final_T,
                        const uint32_t* n_contrib, const float* dL_dpix, float* dL_dsplat,
-                       void* zero_fill, size_t zero_fill_bytes, void* start_event, void* stop_event,
-                       void* stream);
+                       uint8_t* touched, void* zero_fill, size_t zero_fill_bytes, void* start_event,
+                       void* stop_event, void* stream);
 
 /* ---- Kernel-exact timing of the two blend kernels ----------------------------
  * The same calls with a pair of events (hipEvent_t passed as void*, from
@@ -360,7 +364,10 @@ int gsr_blend_bwd_timed(int W, int H, const uint32_t* ranges, const uint32_t* po
  * the Gaussian's row of dL_dsplat, so a Gaussian with an all-zero row (culled, or
  * never blended because it is hidden: most Gaussians of a dense scene) has zero
  * gradients; the kernel then writes only the rows of the others and skips the
- * 248 bytes of zeros per Gaussian that dominate its traffic otherwise. */
+ * 248 bytes of zeros per Gaussian that dominate its traffic otherwise.
+ * touched (optional, only with outputs_zeroed; P bytes as written by
+ * gsr_blend_bwd_fill): a Gaussian whose byte is 0 is taken to have an all-zero
+ * row without the row being read (64 bytes per Gaussian less to scan). */
 int gsr_preprocess_bwd(int P, int D, int M, const float* means3D, const float* scales,
                        float scale_modifier, const float* rotations, const float* shs,
                        const float* cov3D_precomp, const float* viewmatrix,
@@ -368,7 +375,8 @@ int gsr_preprocess_bwd(int P, int D, int M, const float* means3D, const float* s
                        float tanfovy, const uint32_t* records, const float* dL_dsplat,
                        float* dL_dmeans3D, float* dL_dmeans2D, float* dL_dopacities,
                        float* dL_dshs, float* dL_dcolors, float* dL_dscales,
-                       float* dL_drotations, float* dL_dcov3D, int outputs_zeroed, void* stream);
+                       float* dL_drotations, float* dL_dcov3D, int outputs_zeroed,
+                       const uint8_t* touched, void* stream);
 
 /* ---- Raw-parameter variants of the per-Gaussian stages -----------------------
  * The reference applies its activations in separate PyTorch kernels on every
@@ -394,7 +402,8 @@ int gsr_preprocess_bwd_raw(int P, int D, int n_rest, const float* xyz, const flo
                            int W, int H, float tanfovx, float tanfovy, const uint32_t* records,
                            const float* dL_dsplat, float* dL_dxyz, float* dL_dmeans2D,
                            float* dL_dopacity_raw, float* dL_dfeatures_dc, float* dL_dfeatures_rest,
-                           float* dL_dscaling_raw, float* dL_drotation_raw, int outputs_zeroed, void* stream);
+                           float* dL_dscaling_raw, float* dL_drotation_raw, int outputs_zeroed,
+                           const uint8_t* touched, void* stream);
 
 /* ---- Photometric loss ------------------------------------------------------
  * The step that follows the rasterizer in every training iteration

@@ -263,6 +263,7 @@ def test_the_blend_kernels_clear_what_the_backward_wants_zeroed():
         assert int(st.dsplat.view(torch.int32).abs().max()) == 0
         held = st.zeroed_grads
         assert held is not None and not held.cleared
+        assert held.touched.shape[0] >= c.xyz.shape[0] and int(held.touched.max()) == 0   # cleared with the accumulator
         dsplat = dgr.blend_backward(st, torch.zeros_like(st.color))
         torch.cuda.synchronize()
         assert held.cleared == rendered
@@ -277,8 +278,9 @@ def test_the_blend_kernels_clear_what_the_backward_wants_zeroed():
 
 
 def test_blend_backward_with_a_zero_fill_through_the_c_abi():
-    """gsr_blend_bwd_fill against gsr_blend_bwd: the same sums (up to the order of the atomic additions), and
-    the fill is all zeros, for sizes that do not divide by the number of workgroups and for one smaller than it."""
+    """gsr_blend_bwd_fill against gsr_blend_bwd: the same sums (up to the order of the atomic additions), the
+    fill is all zeros, for sizes that do not divide by the number of workgroups and for one smaller than it, and
+    every Gaussian with a non-zero row of sums has its `touched` byte set (no byte beyond the P is written)."""
     import ctypes as C
     import diff_gaussian_rasterization as dgr
     cloud, cam, bg, _ = make_scene(20_000, 333, 222, sh_degree=0, seed=5, coeffs=1)
@@ -295,16 +297,22 @@ def test_blend_backward_with_a_zero_fill_through_the_c_abi():
         guard = 64
         buf = torch.full((nbytes // 4 + 2 * guard,), float("nan"), device="cuda")
         got = torch.zeros((st.P, 16), device="cuda")
-        rc = lib.gsr_blend_bwd_fill(*common, p(got), C.c_void_p(buf.data_ptr() + 4 * guard), nbytes, None, None, stream)
+        touched = torch.zeros((st.P + guard,), dtype=torch.uint8, device="cuda")
+        rc = lib.gsr_blend_bwd_fill(*common, p(got), p(touched), C.c_void_p(buf.data_ptr() + 4 * guard), nbytes, None, None,
+                                    stream)
         assert rc == 0, lib.gsr_last_error().decode()
         torch.cuda.synchronize()
+        has_sums = (got != 0).any(dim=1)
+        assert int(has_sums.sum()) > 100 and bool((touched[:st.P][has_sums] == 1).all())
+        assert int(touched.max()) == 1 and int(touched[st.P:].max()) == 0
+        assert int(touched.sum()) < st.P                     # hidden and culled Gaussians stay unmarked
         assert int(buf[guard:-guard].view(torch.int32).abs().max()) == 0
         assert bool(torch.isnan(buf[:guard]).all()) and bool(torch.isnan(buf[-guard:]).all())   # nothing beyond it
         assert float((got - plain).abs().max()) <= 1e-5 * float(plain.abs().max())   # atomic additions in another order
     # misaligned or ragged fills are refused
     buf = torch.zeros((64,), device="cuda")
-    assert lib.gsr_blend_bwd_fill(*common, p(plain), C.c_void_p(buf.data_ptr() + 4), 16, None, None, stream) != 0
-    assert lib.gsr_blend_bwd_fill(*common, p(plain), p(buf), 24, None, None, stream) != 0
+    assert lib.gsr_blend_bwd_fill(*common, p(plain), None, C.c_void_p(buf.data_ptr() + 4), 16, None, None, stream) != 0
+    assert lib.gsr_blend_bwd_fill(*common, p(plain), None, p(buf), 24, None, None, stream) != 0
 
 
 def test_two_host_threads_on_their_own_streams():
