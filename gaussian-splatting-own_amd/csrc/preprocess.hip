@@ -433,37 +433,11 @@ __device__ __forceinline__ void store_f4(float* dst, const float* v) {
   for (int k = 0; k < N / 4; k++) d[k] = make_float4(v[4 * k], v[4 * k + 1], v[4 * k + 2], v[4 * k + 3]);
 }
 
-template <int D>
-__global__ void __launch_bounds__(kBlock, 4) preprocess_bwd_kernel(BwdArgs a) {
-  extern __shared__ float rest_tile[];   // the block's rows of the SH gradient (raw mode: of _features_rest), stored coalesced
-  int i = blockIdx.x * kBlock + threadIdx.x;
-  if (a.sparse) {
-    // The outputs are zero already, so only the Gaussians with gradients have anything to do, and in a dense
-    // scene those are a few per cent.  They are moved to the block's first lanes: one wave then runs the long
-    // arithmetic below for them instead of all four running it with two or three lanes switched on.
-    __shared__ int s_active[kBlock];
-    __shared__ int s_waves[kBlock / 64];
-    bool active = false;
-    if (i < a.P && (a.touched == nullptr || a.touched[i] != 0)) {
-      const float4* row = reinterpret_cast<const float4*>(a.dL_dsplat) + (size_t)i * (GSR_GRAD_WORDS / 4);
-      const float4 r0 = row[0], r1 = row[1];
-      const float r2 = reinterpret_cast<const float*>(row)[8];
-      active = (r0.x != 0.f) | (r0.y != 0.f) | (r0.z != 0.f) | (r0.w != 0.f) | (r1.x != 0.f) | (r1.y != 0.f) |
-               (r1.z != 0.f) | (r1.w != 0.f) | (r2 != 0.f);
-    }
-    const unsigned long long votes = __ballot(active);
-    const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
-    if (lane == 0) s_waves[wave] = __popcll(votes);
-    __syncthreads();
-    int before = 0, total = 0;
-#pragma unroll
-    for (int w = 0; w < kBlock / 64; w++) { before += w < wave ? s_waves[w] : 0; total += s_waves[w]; }
-    if (active) s_active[before + __popcll(votes & ((1ull << lane) - 1ull))] = i;
-    __syncthreads();
-    if ((int)threadIdx.x >= total) return;
-    i = s_active[threadIdx.x];
-  }
-  const bool valid = i < a.P;
+// The gradients of Gaussian i (valid: i < P).  SPARSE: the outputs were zero when the kernel started and only a
+// Gaussian with gradients writes, each its own rows; otherwise every row is written, the SH gradient through the
+// workgroup's LDS tile (rest_tile), which every thread of the workgroup must then reach.
+template <int D, bool SPARSE>
+__device__ __forceinline__ void bwd_one_gaussian(const BwdArgs& a, const int i, const bool valid, float* rest_tile) {
   // Every gradient of this kernel is linear in the nine sums the blend backward left for the Gaussian.  A
   // Gaussian that no pixel blended (culled, or hidden behind saturated pixels: most of a dense scene) has nine
   // zeros, hence zero gradients: nothing else of it is loaded, not even its record.  (NaN != 0, so a poisoned
@@ -677,7 +651,7 @@ __global__ void __launch_bounds__(kBlock, 4) preprocess_bwd_kernel(BwdArgs a) {
     dopac = dopac * (o * (1.0f - o));
   }
 
-  if (a.sparse) {
+  if (SPARSE) {
     // the outputs were zero when the kernel started: only the Gaussians with gradients write, each its own rows
     if (!vis) return;
     if (a.dL_dshs_rest) {
@@ -747,6 +721,71 @@ __global__ void __launch_bounds__(kBlock, 4) preprocess_bwd_kernel(BwdArgs a) {
 #pragma unroll
     for (int k = 0; k < 6; k++) a.dL_dcov3D[6 * (size_t)i + k] = dc6[k];
   }
+}
+
+template <int D>
+__global__ void __launch_bounds__(kBlock, 4) preprocess_bwd_kernel(BwdArgs a) {
+  extern __shared__ float rest_tile[];   // the block's rows of the SH gradient (raw mode: of _features_rest), stored coalesced
+  const int i = blockIdx.x * kBlock + threadIdx.x;
+  bwd_one_gaussian<D, false>(a, i, i < a.P, rest_tile);
+}
+
+// The outputs are zero already, so only the Gaussians with gradients have anything to do, and in a dense scene
+// those are a few per cent.  One wave per workgroup looks at kSparseSpan Gaussians (four per lane: the flags the
+// blend backward left, then the rows of sums of the flagged ones), lists those with a non-zero row in LDS, and
+// runs the long arithmetic for the listed ones, 64 at a time.  One-wave workgroups because that arithmetic
+// takes 128 registers: a wave of it per workgroup of four would leave three quarters of a CU's wave slots
+// to workgroups that are already done with their look, and the kernel is a chain of dependent loads per wave.
+constexpr int kSparseSpan = 256;
+
+template <int D>
+__global__ void __launch_bounds__(64, 4) preprocess_bwd_sparse_kernel(BwdArgs a) {
+  __shared__ int s_active[kSparseSpan];
+  const int lane = threadIdx.x;
+  const int first = blockIdx.x * kSparseSpan + 4 * lane;
+  uint32_t flags = 0u;                       // byte k: Gaussian first + k may have a non-zero row
+  if (first + 3 < a.P) {
+    flags = a.touched ? *reinterpret_cast<const uint32_t*>(a.touched + first) : 0x01010101u;
+  } else {
+    for (int k = 0; k < 4; k++)
+      if (first + k < a.P && (a.touched == nullptr || a.touched[first + k] != 0)) flags |= 1u << (8 * k);
+  }
+  bool active[4];
+#pragma unroll
+  for (int k = 0; k < 4; k++) {
+    active[k] = false;
+    if ((flags >> (8 * k)) & 0xFFu) {
+      const float4* row = reinterpret_cast<const float4*>(a.dL_dsplat) + (size_t)(first + k) * (GSR_GRAD_WORDS / 4);
+      const float4 r0 = row[0], r1 = row[1];
+      const float r2 = reinterpret_cast<const float*>(row)[8];
+      active[k] = (r0.x != 0.f) | (r0.y != 0.f) | (r0.z != 0.f) | (r0.w != 0.f) | (r1.x != 0.f) | (r1.y != 0.f) |
+                  (r1.z != 0.f) | (r1.w != 0.f) | (r2 != 0.f);
+    }
+  }
+  int total = 0;
+#pragma unroll
+  for (int k = 0; k < 4; k++) {
+    const unsigned long long votes = __ballot(active[k]);
+    if (active[k]) s_active[total + __popcll(votes & ((1ull << lane) - 1ull))] = first + k;
+    total += __popcll(votes);
+  }
+  __syncthreads();
+  for (int at = 0; at < total; at += 64) {
+    const bool valid = at + lane < total;
+    bwd_one_gaussian<D, true>(a, valid ? s_active[at + lane] : 0, valid, nullptr);
+  }
+}
+
+int launch_sparse_bwd(int degree, const BwdArgs& a, hipStream_t st) {
+  GSR_REQUIRE(((uintptr_t)a.touched & 3) == 0, "preprocess_bwd: touched must be 4-byte aligned");
+  const dim3 grid(gsr::div_up(a.P, kSparseSpan)), block(64);
+  switch (degree) {
+    case 0: hipLaunchKernelGGL(preprocess_bwd_sparse_kernel<0>, grid, block, 0, st, a); break;
+    case 1: hipLaunchKernelGGL(preprocess_bwd_sparse_kernel<1>, grid, block, 0, st, a); break;
+    case 2: hipLaunchKernelGGL(preprocess_bwd_sparse_kernel<2>, grid, block, 0, st, a); break;
+    default: hipLaunchKernelGGL(preprocess_bwd_sparse_kernel<3>, grid, block, 0, st, a); break;
+  }
+  return gsr::check_launch("preprocess_bwd (sparse)");
 }
 
 }  // namespace
@@ -841,7 +880,8 @@ extern "C" int gsr_preprocess_bwd(int P, int D, int M, const float* means3D, con
   hipStream_t st = (hipStream_t)stream;
   dim3 grid(gsr::div_up(P, kBlock)), block(kBlock);
   const int d = shs ? D : 0;
-  const size_t lds = (shs && !a.sparse) ? (size_t)kBlock * (M * 3 + 1) * sizeof(float) : 0;     // the block's tile of the SH gradient
+  if (a.sparse) return launch_sparse_bwd(d, a, st);
+  const size_t lds = shs ? (size_t)kBlock * (M * 3 + 1) * sizeof(float) : 0;     // the block's tile of the SH gradient
   switch (d) {
     case 0: hipLaunchKernelGGL(preprocess_bwd_kernel<0>, grid, block, lds, st, a); break;
     case 1: hipLaunchKernelGGL(preprocess_bwd_kernel<1>, grid, block, lds, st, a); break;
@@ -914,7 +954,8 @@ extern "C" int gsr_preprocess_bwd_raw(int P, int D, int n_rest, const float* xyz
   hipStream_t st = (hipStream_t)stream;
   dim3 grid(gsr::div_up(P, kBlock)), block(kBlock);
   // the block's tile of the SH gradient: the rows of features_rest, or of features_dc when there is no rest tensor
-  const size_t lds = a.sparse ? 0 : (size_t)kBlock * (split ? n_rest * 3 : 3 + 1) * sizeof(float);
+  if (a.sparse) return launch_sparse_bwd(D, a, st);
+  const size_t lds = (size_t)kBlock * (split ? n_rest * 3 : 3 + 1) * sizeof(float);
   switch (D) {
     case 0: hipLaunchKernelGGL(preprocess_bwd_kernel<0>, grid, block, lds, st, a); break;
     case 1: hipLaunchKernelGGL(preprocess_bwd_kernel<1>, grid, block, lds, st, a); break;
