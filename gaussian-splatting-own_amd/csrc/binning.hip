@@ -69,44 +69,13 @@ using gsr::Pack;
 // ---------------------------------------------------------------------------
 // totals: N = tile instances, E1 = supercell entries, E2 = cell entries, V = visible Gaussians
 // ---------------------------------------------------------------------------
-__device__ __forceinline__ uint32_t wave_sum(uint32_t v) {
-#pragma unroll
-  for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o);
-  return v;
-}
-
 // Sums the per-block partial records the preprocess geometry kernel leaves behind.
 // totals[4] = the caller's status word as it stands (0 without one): it rides to the host with the sizes.
 __global__ void __launch_bounds__(kScanBlock) totals_final_kernel(int blocks, const uint32_t* __restrict__ partials,
                                                                   const uint32_t* __restrict__ status,
                                                                   uint32_t* __restrict__ totals) {
   __shared__ uint32_t s_part[kScanBlock / 64][4];
-  uint32_t acc[4] = {0u, 0u, 0u, 0u};
-  // four independent 16-byte loads per thread and round
-  for (int b0 = threadIdx.x; b0 < blocks; b0 += 4 * kScanBlock) {
-    uint4 p[4];
-#pragma unroll
-    for (int k = 0; k < 4; k++) {
-      const int b = b0 + k * kScanBlock;
-      p[k] = b < blocks ? reinterpret_cast<const uint4*>(partials)[b] : make_uint4(0u, 0u, 0u, 0u);
-    }
-#pragma unroll
-    for (int k = 0; k < 4; k++) { acc[0] += p[k].x; acc[1] += p[k].y; acc[2] += p[k].z; acc[3] += p[k].w; }
-  }
-  const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
-#pragma unroll
-  for (int k = 0; k < 4; k++) {
-    acc[k] = wave_sum(acc[k]);
-    if (lane == 0) s_part[wave][k] = acc[k];
-  }
-  __syncthreads();
-  if (threadIdx.x < 4) {
-    uint32_t t = 0;
-#pragma unroll
-    for (int w = 0; w < kScanBlock / 64; w++) t += s_part[w][threadIdx.x];
-    totals[threadIdx.x] = t;
-  }
-  if (threadIdx.x == 4) totals[4] = status ? *status : 0u;
+  gsr::sum_totals<kScanBlock>(blocks, partials, status, totals, s_part);
 }
 
 // ---------------------------------------------------------------------------

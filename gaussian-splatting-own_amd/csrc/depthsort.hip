@@ -90,16 +90,20 @@ __device__ __forceinline__ uint32_t wave_incl_scan(uint32_t v) {
   return v;
 }
 
-// Clears the histograms, control words and look-back states.  With mirror_dst, the first workgroup also
-// copies eight words (the list sizes and the carried status of the preprocess) to host-visible memory: the
-// read-back then costs no copy command between the preprocess and the sort, only this kernel's own stores,
-// which are pushed out to the host before the wave ends.
-__global__ void __launch_bounds__(256) sort_clear_kernel(uint32_t* __restrict__ words, size_t n,
-                                                         const uint32_t* __restrict__ mirror_src,
-                                                         uint32_t* __restrict__ mirror_dst) {
-  if (mirror_dst != nullptr && blockIdx.x == 0 && threadIdx.x < 8) {
-    mirror_dst[threadIdx.x] = mirror_src[threadIdx.x];
+// Clears the histograms, control words and look-back states.  With a mirror, the first workgroup first
+// finishes the list sizes of the preprocess and sends them to the host (see SortMirror): the read-back then
+// costs neither a kernel of its own, nor a copy command between the preprocess and the sort, nor an event.
+__global__ void __launch_bounds__(256) sort_clear_kernel(uint32_t* __restrict__ words, size_t n, gsr::SortMirror m) {
+  if (m.dst != nullptr && blockIdx.x == 0) {
+    __shared__ uint32_t s_part[256 / 64][4];
+    const uint32_t mine = gsr::sum_totals<256>(m.blocks, m.partials, m.status, m.totals, s_part);
+    if (threadIdx.x < 7) m.dst[threadIdx.x] = mine;          // words 5 and 6 are spare: 0
     __threadfence_system();
+    __syncthreads();
+    if (threadIdx.x == 0) {
+      m.dst[7] = m.ticket;                                    // behind the sizes
+      __threadfence_system();
+    }
   }
   for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (size_t)gridDim.x * 256) words[i] = 0u;
 }
@@ -498,11 +502,7 @@ int depth_sort(int P, const uint32_t* keys, const uint64_t* vals, uint64_t* sort
   u64* vb = (u64*)(base + L.vals_b);
   const unsigned clear_blocks = (unsigned)((L.clear_words + 1023) / 1024 < 1024 ? (L.clear_words + 1023) / 1024 : 1024);
   hipLaunchKernelGGL(sort_clear_kernel, dim3(clear_blocks), dim3(256), 0, st, hist, L.clear_words,
-                     mirror ? mirror->src : nullptr, mirror ? mirror->dst : nullptr);
-  if (mirror && mirror->event) {
-    const hipError_t e = hipEventRecord(mirror->event, st);
-    if (e != hipSuccess) return gsr::fail(GSR_E_LAUNCH, "depth_sort: event: %s", hipGetErrorString(e));
-  }
+                     mirror ? *mirror : gsr::SortMirror{nullptr, 0, nullptr, nullptr, nullptr, 0u});
   const unsigned hist_wanted = ((unsigned)P + 4095u) / 4096u;
   // 512: measured against 32 .. 2048 at 1M and 6M keys (fewer blocks serialise the LDS counting, more only add flush atomics)
   const unsigned hist_blocks = hist_wanted < 512u ? hist_wanted : 512u;

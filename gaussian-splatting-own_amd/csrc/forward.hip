@@ -4,6 +4,7 @@
 // are theirs bit for bit.  The point of it is the host side: one transition into native code per render
 // instead of five, and one workspace instead of a dozen buffers, which is what a render of 100k
 // Gaussians spends as much time on as on its kernels.
+#include <atomic>
 #include <cstdlib>
 
 #include "gsr_common.h"
@@ -46,6 +47,34 @@ Workspace carve(void* base, int P, int W, int H) {
 
 int hip_fail(const char* what, hipError_t e) { return gsr::fail(GSR_E_LAUNCH, "forward: %s: %s", what, hipGetErrorString(e)); }
 
+// Tickets of the list-size read-back: unique per call in this process, never 0.
+uint32_t next_ticket() {
+  static std::atomic<uint32_t> counter{1u};
+  uint32_t t = counter.fetch_add(1u, std::memory_order_relaxed);
+  return t ? t : counter.fetch_add(1u, std::memory_order_relaxed);
+}
+
+// Spins until the GPU has stored `ticket` at landing[7] (behind the sizes at landing[0..4]).  Every few thousand
+// looks the stream is asked how it is: an error ends the wait, and so does a stream that has run dry without
+// the ticket having arrived.
+int await_ticket(const uint32_t* landing, uint32_t ticket, hipStream_t st) {
+  const volatile uint32_t* word = landing + 7;
+  for (uint32_t looks = 1;; looks++) {
+    if (*word == ticket) break;
+    if ((looks & 0xFFFu) == 0u) {
+      const hipError_t q = hipStreamQuery(st);
+      if (q == hipSuccess) {
+        if (*word == ticket) break;
+        return gsr::fail(GSR_E_LAUNCH, "forward: the list sizes never arrived in the landing buffer");
+      }
+      if (q != hipErrorNotReady) return hip_fail("waiting for the list sizes", q);
+    }
+    __builtin_ia32_pause();
+  }
+  std::atomic_thread_fence(std::memory_order_acquire);
+  return GSR_OK;
+}
+
 }  // namespace
 
 extern "C" size_t gsr_forward_workspace_bytes(int P, int W, int H) {
@@ -79,7 +108,19 @@ extern "C" int gsr_forward(const GsrForwardArgs* a, gsr_resize_fn resize, void* 
   GSR_REQUIRE(a->zero_fill_bytes == 0 || (a->zero_fill && ((uintptr_t)a->zero_fill & 15) == 0 && a->zero_fill_bytes % 16 == 0),
               "forward: the zero-fill must be 16-byte aligned and a multiple of 16 bytes");
   if (P > 0) {
+    // The list sizes (and the carried status word) travel to the host while the GPU sorts by depth.  When
+    // the landing buffer is pinned memory the GPU can address, the sort's first kernel sums the preprocess's
+    // partial records and stores the sizes there itself, followed by a ticket the host polls for; otherwise
+    // the preprocess sums them in a kernel of its own and a copy command goes ahead of the sort.
+    static const bool copy_always = getenv("GSR_COPY_READBACK") != nullptr;   // for measurements of the difference
+    void* landing = nullptr;
+    hipError_t e = copy_always ? hipErrorInvalidValue : hipHostGetDevicePointer(&landing, a->h_totals, 0);
+    if (e != hipSuccess) {
+      (void)hipGetLastError();
+      landing = nullptr;
+    }
     int rc;
+    gsr::defer_totals(landing != nullptr);
     if (a->raw)
       rc = gsr_preprocess_fwd_raw(P, a->D, a->M - 1, a->means3D, a->scales, a->scale_modifier, a->rotations, a->opacities,
                                   a->shs, a->shs_rest, a->viewmatrix, a->projmatrix, a->campos, W, H, a->tanfovx,
@@ -90,29 +131,28 @@ extern "C" int gsr_forward(const GsrForwardArgs* a, gsr_resize_fn resize, void* 
                               a->colors_precomp, a->cov3D_precomp, a->viewmatrix, a->projmatrix, a->campos, W, H,
                               a->tanfovx, a->tanfovy, a->prefiltered, a->reference_lists, w.records, a->radii, nullptr,
                               w.depth_keys, nullptr, w.sort_vals, w.totals, a->status, a->visible, stream);
+    gsr::defer_totals(false);
     if (rc) return rc;
     if ((rc = checkpoint("preprocess"))) return rc;
     if (a->after_preprocess) a->after_preprocess(a->hook_ctx);
-    // The list sizes (and the carried status word) travel to the host while the GPU sorts by depth.  When
-    // the landing buffer is pinned memory the GPU can address, the sort's first kernel stores them there
-    // itself; otherwise a copy command goes ahead of the sort.
-    static const bool copy_always = getenv("GSR_COPY_READBACK") != nullptr;   // for measurements of the difference
-    void* landing = nullptr;
-    hipError_t e = copy_always ? hipErrorInvalidValue : hipHostGetDevicePointer(&landing, a->h_totals, 0);
-    if (e != hipSuccess) {
-      (void)hipGetLastError();
-      landing = nullptr;
+    if (!landing) {
       e = hipMemcpyAsync(a->h_totals, w.totals, 8 * sizeof(uint32_t), hipMemcpyDeviceToHost, st);
       if (e == hipSuccess) e = hipEventRecord((hipEvent_t)a->event, st);
       if (e != hipSuccess) return hip_fail("read-back of the list sizes", e);
     }
-    const gsr::SortMirror mirror{w.totals, (uint32_t*)landing, (hipEvent_t)a->event};
+    const uint32_t ticket = next_ticket();
+    const gsr::SortMirror mirror{gsr::totals_partials(w.totals), gsr::totals_partial_blocks(P), a->status, w.totals,
+                                 (uint32_t*)landing, ticket};
     rc = gsr::depth_sort(P, w.depth_keys, w.sort_vals, w.sorted_vals, w.sort_scratch, st, landing ? &mirror : nullptr);
     if (rc) return rc;
     sort_error = gsr_bin_sort_error_word(w.sort_scratch);
     if (a->debug && (rc = gsr_bin_sort_status(P, w.sort_scratch, w.sort_bytes, stream))) return rc;
-    e = hipEventSynchronize((hipEvent_t)a->event);
-    if (e != hipSuccess) return hip_fail("waiting for the list sizes", e);
+    if (landing) {
+      if ((rc = await_ticket(a->h_totals, ticket, st))) return rc;
+    } else {
+      e = hipEventSynchronize((hipEvent_t)a->event);
+      if (e != hipSuccess) return hip_fail("waiting for the list sizes", e);
+    }
     N = a->h_totals[0]; E1 = a->h_totals[1]; E2 = a->h_totals[2]; V = a->h_totals[3];
     out->carried_status = a->h_totals[4];
     if (out->carried_status)

@@ -62,24 +62,68 @@ inline Pack make_pack(int P, int tiles_x, int tiles_y) {
   return k;
 }
 
-// A caller's zero-fill riding on kernels that leave most of the GPU idle (one-block prefix sums, the short
-// workgroup chains of the depth sort): the workgroups of a launch from index `first` on clear `vecs` 16-byte
-// words and leave, the others do the kernel's own work.
-// Sums `blocks` partial records of four counters (partials[4 * b + k]) into totals[0..3] and copies
-// the caller's status word (null = 0) to totals[4]; defined with the binning kernels.
+// One workgroup of THREADS threads sums `blocks` partial records of four counters (partials[4 * b + k]) into
+// totals[0..3] and copies the caller's status word (null = 0) to totals[4].  Returns totals[t] to thread t < 5
+// (0 to the others).  s_part: THREADS / 64 rows of LDS.
+template <int THREADS>
+__device__ __forceinline__ uint32_t sum_totals(int blocks, const uint32_t* __restrict__ partials,
+                                               const uint32_t* __restrict__ status, uint32_t* __restrict__ totals,
+                                               uint32_t (*s_part)[4]) {
+  uint32_t acc[4] = {0u, 0u, 0u, 0u};
+  // four independent 16-byte loads per thread and round
+  for (int b0 = threadIdx.x; b0 < blocks; b0 += 4 * THREADS) {
+    uint4 p[4];
+#pragma unroll
+    for (int k = 0; k < 4; k++) {
+      const int b = b0 + k * THREADS;
+      p[k] = b < blocks ? reinterpret_cast<const uint4*>(partials)[b] : make_uint4(0u, 0u, 0u, 0u);
+    }
+#pragma unroll
+    for (int k = 0; k < 4; k++) { acc[0] += p[k].x; acc[1] += p[k].y; acc[2] += p[k].z; acc[3] += p[k].w; }
+  }
+  const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+#pragma unroll
+  for (int k = 0; k < 4; k++) {
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) acc[k] += __shfl_xor(acc[k], o);
+    if (lane == 0) s_part[wave][k] = acc[k];
+  }
+  __syncthreads();
+  uint32_t mine = 0u;
+  if (threadIdx.x < 4) {
+#pragma unroll
+    for (int w = 0; w < THREADS / 64; w++) mine += s_part[w][threadIdx.x];
+    totals[threadIdx.x] = mine;
+  }
+  if (threadIdx.x == 4) totals[4] = mine = status ? *status : 0u;
+  return mine;
+}
+
+// The same as a kernel of one workgroup; defined with the binning kernels.
 int launch_totals_final(int blocks, const uint32_t* partials, const uint32_t* status, uint32_t* totals,
                         hipStream_t stream);
+// gsr_preprocess_fwd[_raw] called from this thread while this is on leaves the partial records unsummed (P > 0);
+// where they are, and how many (defined with the preprocess kernels).
+void defer_totals(bool on);
+int totals_partial_blocks(int P);
+const uint32_t* totals_partials(const uint32_t* totals);
 
 // Depth sort of the binning (defined in depthsort.hip): sorted_vals[0 .. visible) = the values whose
 // key is not 0xFFFFFFFF, by ascending key, equal keys in input order.  scratch: depth_sort_bytes(P)
 // bytes, 256-byte aligned.
 size_t depth_sort_bytes(int P);
-// Optional rider of the sort's first kernel: eight words copied from device memory (src) to host-visible
-// memory (dst, a device-side address of pinned host memory), and an event recorded right behind that kernel.
+// Optional extra duty of the sort's first kernel: the list sizes go to the host from there.  Its first
+// workgroup sums the partial records the preprocess left (as launch_totals_final does: partials, blocks,
+// status, totals), stores totals[0..4] also at dst[0..4] (a device-side address of pinned host memory, eight
+// words), and then the ticket at dst[7]: the host polls that word instead of waiting for an event, which
+// would cost the stream a gap of five microseconds behind the kernel.
 struct SortMirror {
-  const uint32_t* src;
+  const uint32_t* partials;
+  int blocks;
+  const uint32_t* status;
+  uint32_t* totals;
   uint32_t* dst;
-  hipEvent_t event;
+  uint32_t ticket;   // never 0
 };
 int depth_sort(int P, const uint32_t* keys, const uint64_t* vals, uint64_t* sorted_vals, void* scratch,
                hipStream_t stream, const SortMirror* mirror = nullptr);

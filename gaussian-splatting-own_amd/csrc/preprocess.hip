@@ -794,6 +794,16 @@ constexpr int kTotalsHead = 8;   // N, E1, E2, V, status, 3 spare words; the per
 extern "C" size_t gsr_totals_words(int P) { return kTotalsHead + 4 * (size_t)(P > 0 ? gsr::div_up(P, kBlock) : 0); }
 
 namespace {
+// Set by gsr_forward around its call of the preprocess (same thread): the partial records are left as they are,
+// the depth sort's first kernel sums them.
+thread_local bool t_totals_deferred = false;
+}  // namespace
+
+void gsr::defer_totals(bool on) { t_totals_deferred = on; }
+int gsr::totals_partial_blocks(int P) { return P > 0 ? gsr::div_up(P, kBlock) : 0; }
+const uint32_t* gsr::totals_partials(const uint32_t* totals) { return totals + kTotalsHead; }
+
+namespace {
 
 int launch_preprocess_fwd(const char* who, FwdArgs a, int D, uint32_t* totals, const uint32_t* status, void* stream) {
   hipStream_t st = (hipStream_t)stream;
@@ -807,7 +817,7 @@ int launch_preprocess_fwd(const char* who, FwdArgs a, int D, uint32_t* totals, c
     default: hipLaunchKernelGGL(preprocess_fwd_kernel<3>, grid, block, 0, st, a); break;
   }
   int rc = gsr::check_launch(who);
-  if (rc) return rc;
+  if (rc || t_totals_deferred) return rc;
   return gsr::launch_totals_final(blocks, totals + kTotalsHead, status, totals, st);
 }
 

@@ -30,6 +30,22 @@ class PipelineParams:
     fused_activations: bool = False
 
 
+_sink_zeros: dict = {}
+
+
+def _gradient_sink(xyz: torch.Tensor) -> torch.Tensor:
+    """A (P,3) leaf of zeros that requires grad: the sink of gaussian_renderer/__init__.py:26-30.  The zeros are
+    allocated and cleared once per (shape, device) and every call gets a new leaf on the same storage: nothing
+    ever writes the sink's values (the rasterizer only deposits its .grad), so a fill per render would clear
+    12 MB at a million Gaussians for nothing."""
+    key = (tuple(xyz.shape), xyz.device, xyz.dtype)
+    zeros = _sink_zeros.get(key)
+    if zeros is None:
+        _sink_zeros.clear()                       # one size at a time: densification changes P
+        zeros = _sink_zeros[key] = torch.zeros_like(xyz, requires_grad=False)
+    return zeros.detach().requires_grad_(True)
+
+
 def render(viewpoint_camera, pc, pipe: PipelineParams, bg_color: torch.Tensor, scaling_modifier: float = 1.0,
            override_color=None):
     """Returns {"render", "viewspace_points", "visibility_filter", "radii"}.
@@ -38,7 +54,7 @@ def render(viewpoint_camera, pc, pipe: PipelineParams, bg_color: torch.Tensor, s
     # gradient sink for the 2D means (:26-30); the rasterizer deposits (d/dx, d/dy, 0) in its .grad.
     # The reference writes `zeros_like(...) + 0` and retain_grad(); a leaf that requires grad is the
     # same sink without the extra add kernel and without the copy retain_grad makes in backward.
-    screenspace_points = torch.zeros_like(xyz, requires_grad=True)
+    screenspace_points = _gradient_sink(xyz)
 
     settings = GaussianRasterizationSettings(
         image_height=int(viewpoint_camera.image_height), image_width=int(viewpoint_camera.image_width),

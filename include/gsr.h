@@ -248,8 +248,11 @@ int gsr_blend_fwd(int W, int H, const uint32_t* ranges, const uint32_t* point_li
  * page-locked host buffer of 8 words and an event (gsr_event_create) for the
  * read-back, and optionally a status word (see gsr_bin_lists).  When the GPU can
  * address the host buffer (hipHostMalloc / torch pinned memory: the usual case)
- * the depth sort's first kernel stores the eight words there itself and no copy
- * command is issued; pageable memory gets an ordinary copy.  Once the list
+ * the depth sort's first kernel sums the list sizes, stores them there itself,
+ * and behind them a ticket in the buffer's last word, which the call polls for:
+ * no kernel of its own for the sums, no copy command, and the event stays
+ * unused (an event behind that kernel costs the stream five microseconds);
+ * pageable memory gets an ordinary copy and the event.  Once the list
  * sizes have arrived, `resize(resize_ctx, bytes)` is called ONCE for the memory
  * of the tile lists and the list builder's scratch (256-byte aligned device
  * memory, or NULL to fail); it must stay valid as long as the lists are used.

@@ -149,3 +149,30 @@ def test_a_train_step_leaves_nothing_for_the_cyclic_collector(fused):
     finally:
         gc.enable()
     assert len(set(held)) == 1, held
+
+
+def test_every_render_gets_its_own_gradient_sink():
+    """render() hands out a new (P,3) leaf of zeros per call (gaussian_renderer/__init__.py:26-30) on storage that is
+    cleared once: two renders in flight keep separate .grad tensors, the values stay zero, and a cloud of another
+    size gets a sink of its own size."""
+    from gsplat_host.cameras import orbit_camera
+    from gsplat_host.model import GaussianParams
+    from gsplat_host.render import PipelineParams, render
+    from gsplat_host.synthetic import make_cloud
+    dev = torch.device("cuda", 0)
+    bg = torch.zeros(3, device=dev)
+    pipe = PipelineParams(fused_activations=True)
+    model = GaussianParams(make_cloud(3_000, sh_degree=1, seed=3), max_sh_degree=1, device=dev)
+    a = render(orbit_camera(128, 96, angle_deg=0.0, device=dev), model, pipe, bg)
+    b = render(orbit_camera(128, 96, angle_deg=90.0, device=dev), model, pipe, bg)
+    sa, sb = a["viewspace_points"], b["viewspace_points"]
+    assert sa is not sb and sa.is_leaf and sb.is_leaf and sa.requires_grad and sb.requires_grad
+    a["render"].sum().backward()
+    assert sa.grad is not None and sb.grad is None
+    (2.0 * b["render"]).sum().backward()
+    assert sb.grad is not None and sa.grad.data_ptr() != sb.grad.data_ptr()
+    assert float(sa.abs().max()) == 0.0 and float(sb.abs().max()) == 0.0
+    assert float(sa.grad.abs().max()) > 0.0 and not torch.equal(sa.grad, sb.grad)
+    small = GaussianParams(make_cloud(1_000, sh_degree=1, seed=4), max_sh_degree=1, device=dev)
+    c = render(orbit_camera(128, 96, angle_deg=0.0, device=dev), small, pipe, bg)
+    assert c["viewspace_points"].shape == (1_000, 3) and float(c["viewspace_points"].abs().max()) == 0.0
