@@ -348,6 +348,7 @@ def main():
                          "traffic_unit": "bytes/launch (rocprofv3 FETCH_SIZE x2 + WRITE_SIZE)",
                          "kernel_ms": round(dom_ms, 4),
                          "kernel_also_clears_bytes": 248 * P,
+                         "frac_with_the_cleared_bytes": round((alg[dominant] + 248 * P) / (dom_ms * 1e-3) / 1e9 / HBM_PEAK_GBS, 4),
                          "kernel_also_clears": "the gradient tensors of preprocess_bwd (62 floats per Gaussian), a share "
                                                "per workgroup after its own work (gsr_blend_bwd_fill); not counted in "
                                                "the algorithmic bytes, included in kernel_ms",
