@@ -412,3 +412,30 @@ def test_backward_into_cleared_gradients_equals_the_dense_backward(raw):
     again = backward(prepared, sums)                  # a second backward of the same state: the dense way
     for k, v in dense.items():
         assert v is None or torch.equal(again[k], v), k
+
+
+def test_the_single_call_with_a_pageable_landing_buffer():
+    """gsr_forward's read-back of the list sizes has two ways: a landing buffer the GPU can address (pinned: the
+    depth sort's first kernel sums and stores the sizes, the call polls for its ticket) and one it cannot
+    (pageable: the preprocess sums them, a copy command and an event carry them).  Same lists, same image."""
+    import diff_gaussian_rasterization as dgr
+    cloud, cam, bg, _ = make_scene(25_000, 400, 300, sh_degree=2, seed=12, coeffs=9)
+    s = _gpu_settings(cam, bg, 2, 1.0)
+    c = cloud.to("cuda")
+    pinned = _forward(dgr, s, c, single_call=True)
+    slot = dgr._per_device(torch.device("cuda", torch.cuda.current_device()))
+    kept = slot["pinned"]
+    assert kept.is_pinned()
+    slot["pinned"] = torch.full((dgr.TOTALS_HEAD,), -1, dtype=torch.int32)      # ordinary host memory
+    try:
+        pageable = _forward(dgr, s, c, single_call=True)
+        landed = slot["pinned"].tolist()
+    finally:
+        slot["pinned"] = kept
+    assert landed[0] == pageable.num_rendered and landed[3] == pageable.num_visible
+    assert pageable.num_rendered == pinned.num_rendered > 0 and pageable.num_visible == pinned.num_visible
+    assert torch.equal(pageable.point_list, pinned.point_list) and torch.equal(pageable.ranges, pinned.ranges)
+    assert torch.equal(pageable.color, pinned.color)
+    # the pinned way leaves its ticket behind the sizes
+    again = _forward(dgr, s, c, single_call=True)
+    assert int(kept[0]) == again.num_rendered and int(kept[7]) != 0
