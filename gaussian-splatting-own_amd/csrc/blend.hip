@@ -110,19 +110,22 @@ __device__ __forceinline__ void stage_record(Staged* slot, const uint4 r0, const
   *reinterpret_cast<float2*>(&slot->blue) = make_float2(__uint_as_float(r2.z), __uint_as_float(id));
 }
 
-// The backward's slot: the same ten words without the padding, 40 bytes, read and written 8 bytes at a
-// time (a 16-byte access wants 16-byte alignment).  The 2 KB saved per workgroup are what lets a CU
-// hold eight workgroups of the backward instead of seven.
-struct __align__(8) StagedBack {
-  float2 xy, lab, lco, rg, bi;   // (x, y) (la, lb) (lc, opacity) (r, g) (blue, index bits)
+// The backward's staging: the same ten words without the padding (the 2 KB saved per workgroup are what lets a
+// CU hold eight workgroups of the backward instead of seven), as three arrays so that every read is one aligned
+// instruction: 16 bytes, 16 bytes, 8 bytes.  (As one 40-byte slot the words came in as ds_read2_b64 pairs, and a
+// ds_read2_b64 takes the LDS about twice as long as a ds_read_b128 of the same 16 bytes.)
+struct StagedBack {
+  float4 geo[kBatch];    // x, y, -log2e/2 A, -log2e B
+  float4 col[kBatch];    // -log2e/2 C, opacity, r, g
+  float2 tail[kBatch];   // blue, index bits
 };
 
-__device__ __forceinline__ void stage_record(StagedBack* slot, const uint4 r0, const uint4 r1, const uint4 r2, uint32_t id) {
-  slot->xy = make_float2(__uint_as_float(r0.x), __uint_as_float(r0.y));
-  slot->lab = make_float2(-0.5f * kLog2e * __uint_as_float(r1.x), -kLog2e * __uint_as_float(r1.y));
-  slot->lco = make_float2(-0.5f * kLog2e * __uint_as_float(r1.z), __uint_as_float(r1.w));
-  slot->rg = make_float2(__uint_as_float(r2.x), __uint_as_float(r2.y));
-  slot->bi = make_float2(__uint_as_float(r2.z), __uint_as_float(id));
+__device__ __forceinline__ void stage_record(StagedBack& s, int slot, const uint4 r0, const uint4 r1, const uint4 r2, uint32_t id) {
+  s.geo[slot] = make_float4(__uint_as_float(r0.x), __uint_as_float(r0.y), -0.5f * kLog2e * __uint_as_float(r1.x),
+                            -kLog2e * __uint_as_float(r1.y));
+  s.col[slot] = make_float4(-0.5f * kLog2e * __uint_as_float(r1.z), __uint_as_float(r1.w), __uint_as_float(r2.x),
+                            __uint_as_float(r2.y));
+  s.tail[slot] = make_float2(__uint_as_float(r2.z), __uint_as_float(id));
 }
 
 // ---------------------------------------------------------------------------
@@ -312,7 +315,7 @@ __global__ void __launch_bounds__(256) blend_bwd_kernel(int W, int H, const uint
                                                         const float* __restrict__ dL_dpix,
                                                         float* __restrict__ dL_dsplat,
                                                         uint8_t* __restrict__ touched, ShareFill fill) {
-  __shared__ StagedBack s_splat[kBatch];
+  __shared__ __align__(16) StagedBack s_splat;
   __shared__ unsigned long long s_mask[4][4];
   __shared__ int s_last[4];
   __shared__ __align__(16) float s_red[4][8 * kRedStride];   // per wave: 8 rows of 64 lane values
@@ -361,7 +364,7 @@ __global__ void __launch_bounds__(256) blend_bwd_kernel(int W, int H, const uint
       const float sx = __uint_as_float(r0.x), sy = __uint_as_float(r0.y);
       qm = quadrant_mask(sx, sy, __uint_as_float(r0.z), __uint_as_float(r0.w), __uint_as_float(r1.x),
                          __uint_as_float(r1.y), __uint_as_float(r1.z), __uint_as_float(r1.w), tx0, ty0);
-      stage_record(&s_splat[threadIdx.x], r0, r1, r2, g);
+      stage_record(s_splat, (int)threadIdx.x, r0, r1, r2, g);
       // only staged splats can receive sums: the per-Gaussian backward need not look at the rows of the others
       if (touched != nullptr && qm != 0u) touched[g] = 1;
     }
@@ -384,8 +387,8 @@ __global__ void __launch_bounds__(256) blend_bwd_kernel(int W, int H, const uint
         m &= ~(1ull << bit);
         const int j = sw * 64 + bit;
         const int pos = b * kBatch + j;   // 0-based position in the tile list
-        const StagedBack* sp = &s_splat[j];
-        const float2 xy = sp->xy, lab = sp->lab, lco = sp->lco;
+        const float4 geo = s_splat.geo[j], col = s_splat.col[j];
+        const float2 xy = make_float2(geo.x, geo.y), lab = make_float2(geo.z, geo.w), lco = make_float2(col.x, col.y);
         const float dx = xy.x - pxf, dy = xy.y - pyf;
         // same alpha and same keep / skip decision as the forward (min(.99, oG) >= 1/255 exactly when
         // oG >= 1/255), as straight-line code: a pixel that did not blend this splat gets oG = 0,
@@ -400,7 +403,7 @@ __global__ void __launch_bounds__(256) blend_bwd_kernel(int W, int H, const uint
         const float inv = __builtin_amdgcn_rcpf(1.0f - alpha);     // alpha == 0: exactly 1
         T = T * inv;                                               // transmittance in front of the splat
         const float dch = alpha * T;
-        const float2 rg = sp->rg, bi = sp->bi;
+        const float2 rg = make_float2(col.z, col.w), bi = s_splat.tail[j];
         const float d0 = rg.x - acc0, d1 = rg.y - acc1, d2 = bi.x - acc2;
         const float dL_dalpha = (d0 * dp0 + d1 * dp1 + d2 * dp2) * T - (Tf * inv) * bg_dot;
         acc0 = fmaf(alpha, d0, acc0);                              // alpha c + (1 - alpha) acc
