@@ -5,6 +5,7 @@
 // instead of five, and one workspace instead of a dozen buffers, which is what a render of 100k
 // Gaussians spends as much time on as on its kernels.
 #include <atomic>
+#include <chrono>
 #include <cstdlib>
 
 #include "gsr_common.h"
@@ -54,20 +55,23 @@ uint32_t next_ticket() {
   return t ? t : counter.fetch_add(1u, std::memory_order_relaxed);
 }
 
-// Spins until the GPU has stored `ticket` at landing[7] (behind the sizes at landing[0..4]).  Every few thousand
-// looks the stream is asked how it is: an error ends the wait, and so does a stream that has run dry without
-// the ticket having arrived.
+// Spins until the GPU has stored `ticket` at landing[7] (behind the sizes at landing[0..4]).  The stream is asked
+// how it is only once the wait has lasted 20 ms, and then every 20 ms: the query puts a marker into the stream,
+// which costs the GPU five microseconds between the kernels it lands between, and a healthy wait is over in less
+// than a millisecond.  An error ends the wait, and so does a stream that has run dry without the ticket.
 int await_ticket(const uint32_t* landing, uint32_t ticket, hipStream_t st) {
   const volatile uint32_t* word = landing + 7;
+  auto asked = std::chrono::steady_clock::now();
   for (uint32_t looks = 1;; looks++) {
     if (*word == ticket) break;
-    if ((looks & 0xFFFu) == 0u) {
+    if ((looks & 0xFFFu) == 0u && std::chrono::steady_clock::now() - asked > std::chrono::milliseconds(20)) {
       const hipError_t q = hipStreamQuery(st);
       if (q == hipSuccess) {
         if (*word == ticket) break;
         return gsr::fail(GSR_E_LAUNCH, "forward: the list sizes never arrived in the landing buffer");
       }
       if (q != hipErrorNotReady) return hip_fail("waiting for the list sizes", q);
+      asked = std::chrono::steady_clock::now();
     }
     __builtin_ia32_pause();
   }
