@@ -93,25 +93,35 @@ __device__ __forceinline__ uint32_t wave_incl_scan(uint32_t v) {
 // Clears the histograms, control words and look-back states.  With a mirror, the first workgroup first
 // finishes the list sizes of the preprocess and sends them to the host (see SortMirror): the read-back then
 // costs neither a kernel of its own, nor a copy command between the preprocess and the sort, nor an event.
-__global__ void __launch_bounds__(256) sort_clear_kernel(uint32_t* __restrict__ words, size_t n, gsr::SortMirror m) {
-  if (m.dst != nullptr && blockIdx.x == 0) {
-    __shared__ uint32_t s_part[256 / 64][4];
-    const uint32_t mine = gsr::sum_totals<256>(m.blocks, m.partials, m.status, m.totals, s_part);
-    if (threadIdx.x < 7) m.dst[threadIdx.x] = mine;          // words 5 and 6 are spare: 0
+template <int THREADS>
+__device__ __forceinline__ void send_list_sizes(const gsr::SortMirror& m) {
+  __shared__ uint32_t s_part[THREADS / 64][4];
+  const uint32_t mine = gsr::sum_totals<THREADS>(m.blocks, m.partials, m.status, m.totals, s_part);
+  if (threadIdx.x < 7) m.dst[threadIdx.x] = mine;          // words 5 and 6 are spare: 0
+  __threadfence_system();
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    m.dst[7] = m.ticket;                                    // behind the sizes
     __threadfence_system();
-    __syncthreads();
-    if (threadIdx.x == 0) {
-      m.dst[7] = m.ticket;                                    // behind the sizes
-      __threadfence_system();
-    }
   }
+}
+
+__global__ void __launch_bounds__(256) sort_clear_kernel(uint32_t* __restrict__ words, size_t n, gsr::SortMirror m) {
+  if (m.dst != nullptr && blockIdx.x == 0) send_list_sizes<256>(m);
   for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (size_t)gridDim.x * 256) words[i] = 0u;
 }
 
 // Digit histograms of all four passes over the keys of visible Gaussians, and their number.
 __global__ void __launch_bounds__(kThreads) sort_histogram_kernel(const uint32_t* __restrict__ keys, uint32_t P,
                                                                   uint32_t* __restrict__ hist,
-                                                                  uint32_t* __restrict__ ctl) {
+                                                                  uint32_t* __restrict__ ctl, uint32_t own_blocks,
+                                                                  gsr::SortMirror m) {
+  // the first kernel of a sort whose scratch the caller has cleared: the list sizes leave from here, from a
+  // workgroup of their own behind the kernel's own_blocks
+  if (blockIdx.x >= own_blocks) {
+    send_list_sizes<kThreads>(m);
+    return;
+  }
   __shared__ uint32_t s_h[kHistCopyWords];
   __shared__ uint32_t s_valid;
   s_h[threadIdx.x] = 0u;
@@ -119,7 +129,7 @@ __global__ void __launch_bounds__(kThreads) sort_histogram_kernel(const uint32_t
   __syncthreads();
   uint32_t valid = 0;
   constexpr int kPer = 4;   // keys per thread and round, their loads in flight together
-  for (size_t i0 = (size_t)blockIdx.x * (kThreads * kPer); i0 < P; i0 += (size_t)gridDim.x * (kThreads * kPer)) {
+  for (size_t i0 = (size_t)blockIdx.x * (kThreads * kPer); i0 < P; i0 += (size_t)own_blocks * (kThreads * kPer)) {
     uint32_t key[kPer];
 #pragma unroll
     for (int j = 0; j < kPer; j++) {
@@ -490,8 +500,9 @@ size_t depth_sort_bytes(int P) { return P > 0 ? layout((uint32_t)P).total : 256;
 // sorted_vals[0 .. visible) = the values of the keys != 0xFFFFFFFF in ascending key order, equal
 // keys in input order; the rest of sorted_vals is left untouched.
 int depth_sort(int P, const uint32_t* keys, const uint64_t* vals, uint64_t* sorted_vals, void* scratch, hipStream_t st,
-               const SortMirror* mirror) {
+               const SortMirror* mirror, bool cleared) {
   const Layout L = layout((uint32_t)P);
+  const SortMirror no_mirror{nullptr, 0, nullptr, nullptr, nullptr, 0u};
   char* base = (char*)scratch;
   uint32_t* hist = (uint32_t*)base;
   uint32_t* ctl = hist + kHistWords;
@@ -501,12 +512,14 @@ int depth_sort(int P, const uint32_t* keys, const uint64_t* vals, uint64_t* sort
   u64* va = (u64*)(base + L.vals_a);
   u64* vb = (u64*)(base + L.vals_b);
   const unsigned clear_blocks = (unsigned)((L.clear_words + 1023) / 1024 < 1024 ? (L.clear_words + 1023) / 1024 : 1024);
-  hipLaunchKernelGGL(sort_clear_kernel, dim3(clear_blocks), dim3(256), 0, st, hist, L.clear_words,
-                     mirror ? *mirror : gsr::SortMirror{nullptr, 0, nullptr, nullptr, nullptr, 0u});
+  if (!cleared)
+    hipLaunchKernelGGL(sort_clear_kernel, dim3(clear_blocks), dim3(256), 0, st, hist, L.clear_words, mirror ? *mirror : no_mirror);
   const unsigned hist_wanted = ((unsigned)P + 4095u) / 4096u;
   // 512: measured against 32 .. 2048 at 1M and 6M keys (fewer blocks serialise the LDS counting, more only add flush atomics)
   const unsigned hist_blocks = hist_wanted < 512u ? hist_wanted : 512u;
-  hipLaunchKernelGGL(sort_histogram_kernel, dim3(hist_blocks), dim3(kThreads), 0, st, keys, (uint32_t)P, hist, ctl);
+  const bool sizes_here = cleared && mirror;
+  hipLaunchKernelGGL(sort_histogram_kernel, dim3(hist_blocks + (sizes_here ? 1u : 0u)), dim3(kThreads), 0, st, keys, (uint32_t)P,
+                     hist, ctl, hist_blocks, sizes_here ? *mirror : no_mirror);
   const dim3 block(kThreads);
   const uint32_t spin_limit = g_spin_limit.load(std::memory_order_relaxed);
   const uint32_t static_order = L.workgroups <= resident_workgroups(items_per_thread((uint32_t)P)) ? 1u : 0u;
@@ -529,6 +542,11 @@ int depth_sort(int P, const uint32_t* keys, const uint64_t* vals, uint64_t* sort
     default: passes(std::integral_constant<int, kTinyItems>{}); break;
   }
   return gsr::check_launch("depth_sort");
+}
+
+void depth_sort_clear_region(int P, void* scratch, uint32_t** at, size_t* words) {
+  *at = (uint32_t*)scratch;
+  *words = layout((uint32_t)P).clear_words;
 }
 
 // A look-back that ran into its spin limit leaves a bit per pass in the sort's control words.  In that

@@ -124,7 +124,11 @@ extern "C" int gsr_forward(const GsrForwardArgs* a, gsr_resize_fn resize, void* 
       landing = nullptr;
     }
     int rc;
-    gsr::defer_totals(landing != nullptr);
+    // the preprocess's workgroups also clear what the depth sort wants zeroed, which saves the sort its clearing kernel
+    static const bool sort_clears = getenv("GSR_SORT_CLEARS_ITSELF") != nullptr;   // for measurements of the difference
+    gsr::PreprocessExtras extras{landing != nullptr, nullptr, 0};
+    if (!sort_clears) gsr::depth_sort_clear_region(P, w.sort_scratch, &extras.clear_at, &extras.clear_words);
+    gsr::preprocess_extras(&extras);
     if (a->raw)
       rc = gsr_preprocess_fwd_raw(P, a->D, a->M - 1, a->means3D, a->scales, a->scale_modifier, a->rotations, a->opacities,
                                   a->shs, a->shs_rest, a->viewmatrix, a->projmatrix, a->campos, W, H, a->tanfovx,
@@ -135,7 +139,7 @@ extern "C" int gsr_forward(const GsrForwardArgs* a, gsr_resize_fn resize, void* 
                               a->colors_precomp, a->cov3D_precomp, a->viewmatrix, a->projmatrix, a->campos, W, H,
                               a->tanfovx, a->tanfovy, a->prefiltered, a->reference_lists, w.records, a->radii, nullptr,
                               w.depth_keys, nullptr, w.sort_vals, w.totals, a->status, a->visible, stream);
-    gsr::defer_totals(false);
+    gsr::preprocess_extras(nullptr);
     if (rc) return rc;
     if ((rc = checkpoint("preprocess"))) return rc;
     if (a->after_preprocess) a->after_preprocess(a->hook_ctx);
@@ -147,7 +151,7 @@ extern "C" int gsr_forward(const GsrForwardArgs* a, gsr_resize_fn resize, void* 
     const uint32_t ticket = next_ticket();
     const gsr::SortMirror mirror{gsr::totals_partials(w.totals), gsr::totals_partial_blocks(P), a->status, w.totals,
                                  (uint32_t*)landing, ticket};
-    rc = gsr::depth_sort(P, w.depth_keys, w.sort_vals, w.sorted_vals, w.sort_scratch, st, landing ? &mirror : nullptr);
+    rc = gsr::depth_sort(P, w.depth_keys, w.sort_vals, w.sorted_vals, w.sort_scratch, st, landing ? &mirror : nullptr, !sort_clears);
     if (rc) return rc;
     sort_error = gsr_bin_sort_error_word(w.sort_scratch);
     if (a->debug && (rc = gsr_bin_sort_status(P, w.sort_scratch, w.sort_bytes, stream))) return rc;

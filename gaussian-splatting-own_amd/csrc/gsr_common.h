@@ -102,9 +102,17 @@ __device__ __forceinline__ uint32_t sum_totals(int blocks, const uint32_t* __res
 // The same as a kernel of one workgroup; defined with the binning kernels.
 int launch_totals_final(int blocks, const uint32_t* partials, const uint32_t* status, uint32_t* totals,
                         hipStream_t stream);
-// gsr_preprocess_fwd[_raw] called from this thread while this is on leaves the partial records unsummed (P > 0);
-// where they are, and how many (defined with the preprocess kernels).
-void defer_totals(bool on);
+// What gsr_forward asks of the gsr_preprocess_fwd[_raw] it calls (same thread, set around the call; null = nothing):
+// defer_totals: leave the partial records of the list sizes unsummed (P > 0), the depth sort's first kernel sums
+// them; clear_at / clear_words: memory the kernel's workgroups clear as their last act (the depth sort's histograms
+// and look-back states, which then needs no clearing kernel of its own).  Defined with the preprocess kernels,
+// as is where the partial records are and how many.
+struct PreprocessExtras {
+  bool defer_totals;
+  uint32_t* clear_at;
+  size_t clear_words;
+};
+void preprocess_extras(const PreprocessExtras* extras);
 int totals_partial_blocks(int P);
 const uint32_t* totals_partials(const uint32_t* totals);
 
@@ -112,7 +120,8 @@ const uint32_t* totals_partials(const uint32_t* totals);
 // key is not 0xFFFFFFFF, by ascending key, equal keys in input order.  scratch: depth_sort_bytes(P)
 // bytes, 256-byte aligned.
 size_t depth_sort_bytes(int P);
-// Optional extra duty of the sort's first kernel: the list sizes go to the host from there.  Its first
+// Optional extra duty of the sort's first kernel (the clearing kernel, or the histogram kernel when the caller
+// has cleared the scratch): the list sizes go to the host from there.  Its first
 // workgroup sums the partial records the preprocess left (as launch_totals_final does: partials, blocks,
 // status, totals), stores totals[0..4] also at dst[0..4] (a device-side address of pinned host memory, eight
 // words), and then the ticket at dst[7]: the host polls that word instead of waiting for an event, which
@@ -125,8 +134,11 @@ struct SortMirror {
   uint32_t* dst;
   uint32_t ticket;   // never 0
 };
+// cleared: the caller has zeroed depth_sort_clear_region() of the scratch on this stream already.
 int depth_sort(int P, const uint32_t* keys, const uint64_t* vals, uint64_t* sorted_vals, void* scratch,
-               hipStream_t stream, const SortMirror* mirror = nullptr);
+               hipStream_t stream, const SortMirror* mirror = nullptr, bool cleared = false);
+// The words of a sort's scratch that must be zero when it starts.
+void depth_sort_clear_region(int P, void* scratch, uint32_t** at, size_t* words);
 // Waits for the stream, then GSR_OK or GSR_E_SORT for the sort that last used this scratch.
 int depth_sort_status(const void* scratch, hipStream_t stream);
 // Device address of the word that is non-zero after a sort that gave up (inside its scratch).

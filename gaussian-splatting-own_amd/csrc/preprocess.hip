@@ -206,6 +206,7 @@ __device__ __forceinline__ float quat_norm(const float* q) {
 }
 
 struct FwdArgs {
+  uint32_t* clear_at; size_t clear_words;   // memory of the caller's that the workgroups clear as their last act (may be none)
   int raw, n_rest, reference_lists, P, M, W, H;
   const float* means3D; const float* scales; const float* rotations; const float* opacities;
   const float* shs; const float* shs_rest; const float* colors_precomp;
@@ -401,6 +402,7 @@ __global__ void __launch_bounds__(kBlock) preprocess_fwd_kernel(FwdArgs a) {
     for (int w = 0; w < kBlock / 64; w++) t += s_part[w][threadIdx.x];
     a.partials[4 * blockIdx.x + threadIdx.x] = t;
   }
+  for (size_t k = (size_t)blockIdx.x * kBlock + threadIdx.x; k < a.clear_words; k += (size_t)gridDim.x * kBlock) a.clear_at[k] = 0u;
 }
 
 __global__ void __launch_bounds__(kBlock) mark_visible_kernel(int P, const float* __restrict__ means3D,
@@ -794,12 +796,11 @@ constexpr int kTotalsHead = 8;   // N, E1, E2, V, status, 3 spare words; the per
 extern "C" size_t gsr_totals_words(int P) { return kTotalsHead + 4 * (size_t)(P > 0 ? gsr::div_up(P, kBlock) : 0); }
 
 namespace {
-// Set by gsr_forward around its call of the preprocess (same thread): the partial records are left as they are,
-// the depth sort's first kernel sums them.
-thread_local bool t_totals_deferred = false;
+// Set by gsr_forward around its call of the preprocess (same thread).
+thread_local gsr::PreprocessExtras t_extras{false, nullptr, 0};
 }  // namespace
 
-void gsr::defer_totals(bool on) { t_totals_deferred = on; }
+void gsr::preprocess_extras(const PreprocessExtras* extras) { t_extras = extras ? *extras : PreprocessExtras{false, nullptr, 0}; }
 int gsr::totals_partial_blocks(int P) { return P > 0 ? gsr::div_up(P, kBlock) : 0; }
 const uint32_t* gsr::totals_partials(const uint32_t* totals) { return totals + kTotalsHead; }
 
@@ -817,7 +818,7 @@ int launch_preprocess_fwd(const char* who, FwdArgs a, int D, uint32_t* totals, c
     default: hipLaunchKernelGGL(preprocess_fwd_kernel<3>, grid, block, 0, st, a); break;
   }
   int rc = gsr::check_launch(who);
-  if (rc || t_totals_deferred) return rc;
+  if (rc || t_extras.defer_totals) return rc;
   return gsr::launch_totals_final(blocks, totals + kTotalsHead, status, totals, st);
 }
 
@@ -845,7 +846,7 @@ extern "C" int gsr_preprocess_fwd(int P, int D, int M, const float* means3D, con
   GSR_REQUIRE(W <= 16 * 16 * 255 && H <= 16 * 16 * 255, "preprocess_fwd: image %dx%d too large", W, H);
   const gsr::Pack pack = gsr::make_pack(P, gsr::div_up(W, GSR_TILE_X), gsr::div_up(H, GSR_TILE_Y));
   GSR_REQUIRE(pack.bits() <= 64, "preprocess_fwd: %d Gaussians on a %dx%d image do not fit the 64-bit sort value", P, W, H);
-  FwdArgs a{0, 0, reference_lists, P, M, W, H, means3D, scales, rotations, opacities, shs, nullptr, colors_precomp, cov3D_precomp,
+  FwdArgs a{t_extras.clear_at, t_extras.clear_words, 0, 0, reference_lists, P, M, W, H, means3D, scales, rotations, opacities, shs, nullptr, colors_precomp, cov3D_precomp,
             viewmatrix, projmatrix, campos, scale_modifier, tanfovx, tanfovy, pack, records, radii, tiles_touched,
             depth_keys, rects, (unsigned long long*)sort_vals, nullptr, visible};
   return launch_preprocess_fwd("preprocess_fwd", a, D, totals, status, stream);
@@ -930,7 +931,7 @@ extern "C" int gsr_preprocess_fwd_raw(int P, int D, int n_rest, const float* xyz
   GSR_REQUIRE(pack.bits() <= 64, "preprocess_fwd_raw: %d Gaussians on a %dx%d image do not fit the 64-bit sort value", P,
               W, H);
   // with no rest tensor the dc tensor alone is a (P,1,3) shs tensor
-  FwdArgs a{1, n_rest, reference_lists, P, 1 + n_rest, W, H, xyz, scaling_raw, rotation_raw, opacity_raw, features_dc,
+  FwdArgs a{t_extras.clear_at, t_extras.clear_words, 1, n_rest, reference_lists, P, 1 + n_rest, W, H, xyz, scaling_raw, rotation_raw, opacity_raw, features_dc,
             n_rest > 0 ? features_rest : nullptr, nullptr, nullptr, viewmatrix, projmatrix, campos, scale_modifier,
             tanfovx, tanfovy, pack, records, radii, tiles_touched, depth_keys, rects, (unsigned long long*)sort_vals,
             nullptr, visible};
