@@ -120,7 +120,7 @@ def test_list_builder_refuses_a_failed_sort_and_foreign_sizes():
     sort_vals = torch.empty((P,), dtype=torch.int64, device="cuda")
     dgr._run("preprocess_fwd", lib.gsr_preprocess_fwd, P, 0, 1, ptr(c.xyz), ptr(c.scaling), 1.0, ptr(c.rotation),
              ptr(c.opacity), ptr(c.features), None, None, ptr(st.view), ptr(st.proj), ptr(st.campos), W, H,
-             float(s.tanfovx), float(s.tanfovy), 0, 1, ptr(records), ptr(radii), None, ptr(keys), None, ptr(sort_vals),
+             float(s.tanfovx), float(s.tanfovy), 0, int(dgr.REFERENCE_LISTS), ptr(records), ptr(radii), None, ptr(keys), None, ptr(sort_vals),
              ptr(totals), None, None, dgr._stream())
     n, e1, e2, v = (int(x) for x in totals[:4].tolist())
     assert (n, v) == (N, V) and int(totals[4]) == 0
