@@ -108,3 +108,33 @@ def test_scratch_and_size_checks_come_before_any_launch():
     assert rc != 0 and b"scratch too small" in lib.gsr_last_error()
     rc = lib.gsr_bin_lists(1000, 900, 5000, 950, 3000, 70000, 480, fake, fake, fake, None, None, None, None, fake, 1 << 24, None)
     assert rc == -1 and b"too large" in lib.gsr_last_error()
+
+
+def test_the_backward_block_is_laid_out_as_the_library_expects():
+    """Host logic of the binding, no GPU: the one allocation a prepared forward makes for its backward holds the
+    (P,16) accumulator first, the P `touched` bytes behind it, then every gradient tensor, all on 256-byte
+    boundaries and none overlapping; what the forward clears is the accumulator and the flags, the rest is
+    what the blend backward clears."""
+    import torch
+    import diff_gaussian_rasterization as dgr
+    for P, shapes in ((1, dgr._gradient_shapes(1, True, n_rest=15)), (1001, dgr._gradient_shapes(1001, True, n_rest=0)),
+                      (777, dgr._gradient_shapes(777, False, M=16)), (64, dgr._gradient_shapes(64, False, colors=True, cov3D=True))):
+        block, dsplat, touched, views = dgr._carve_zero_block(P, shapes, torch.device("cpu"))
+        base, end = block.data_ptr(), block.data_ptr() + block.numel() * 4
+        assert dsplat.data_ptr() == base and dsplat.shape == (P, 16)
+        assert touched.dtype == torch.uint8 and touched.numel() >= P
+        spans = [(dsplat.data_ptr(), dsplat.numel() * 4), (touched.data_ptr(), touched.numel())]
+        assert set(views) == set(shapes)
+        for name, v in views.items():
+            assert tuple(v.shape) == tuple(shapes[name]) and v.is_contiguous() and v.dtype == torch.float32
+            spans.append((v.data_ptr(), v.numel() * 4))
+        spans.sort()
+        for (a, n), (b, _) in zip(spans, spans[1:]):
+            assert (a - base) % 256 == 0 and a + n <= b
+        assert (spans[-1][0] - base) % 256 == 0 and spans[-1][0] + spans[-1][1] <= end
+        first_grad = min(v.data_ptr() for v in views.values())
+        assert touched.data_ptr() + touched.numel() <= first_grad and (first_grad - base) % 16 == 0
+        # writing one piece leaves the others alone
+        block.zero_()
+        views[next(iter(views))].fill_(1.0)
+        assert float(dsplat.abs().max()) == 0.0 and int(touched.max()) == 0
