@@ -10,8 +10,9 @@ backward.  The optimiser step is outside that span in the reference
 configuration: 1M synthetic Gaussians, 1920x1080, SH degree 3 (see
 gsplat_host/synthetic.py for the seeded recipe).  With --gpus N (launched by
 torch.distributed.run, one rank per GPU) every rank renders its own view of the
-same replicated cloud (camera rotated by rank*45 degrees) and the scalar loss is
-all-reduced over RCCL: per-GPU work is fixed, scaling is weak.
+same replicated cloud (camera rotated by rank*45 degrees); the path has no exchange
+between the ranks, the mean loss of the timed steps is all-reduced over RCCL once,
+before the closing barrier: per-GPU work is fixed, scaling is weak.
 
 Rank 0 prints ONE JSON line.  `value` is render throughput, Msplats/s = Gaussians
 submitted per second of forward render (preprocess + binning + blend), summed
@@ -166,7 +167,7 @@ def measure(scene, dgr, fused, steps, warmup, use_dist=False, dp_grads=False, op
     timer = dgr.StageTimer(only=(), exact=dgr.StageTimer.EXACT_STAGES)
     all_stages = dgr.StageTimer()
     fwd_events = []
-    state = {"pending": None, "grad_scale": 1.0, "out": None}
+    state = {"losses": [], "mean_loss": None, "grad_scale": 1.0, "out": None}
 
     def step(timed):
         for p in scene.params:
@@ -181,24 +182,25 @@ def measure(scene, dgr, fused, steps, warmup, use_dist=False, dp_grads=False, op
         loss = photometric_loss(out["render"], scene.gt)
         loss.backward()
         if use_dist:
-            # RCCL over xGMI: one fp32 scalar.  Nothing in the next step needs the mean loss, so the
-            # collective runs on RCCL's own stream beside it; the previous one is waited for first, so
-            # at most one is outstanding, and the last one before the closing barrier.
-            if state["pending"] is not None:
-                state["pending"][0].wait()
-            lv = loss.detach().clone()
-            state["pending"] = (dist.all_reduce(lv, async_op=True), lv)
+            # The render path has no exchange step between the ranks (one view each).  The mean loss over all views
+            # is for the log only: the steps keep their loss tensors and ONE collective (RCCL over xGMI, one fp32
+            # scalar) reduces their mean before the closing barrier.  A collective per step would cost every step
+            # a copy kernel, two stream markers and a kernel that waits for the slowest rank.
+            state["losses"].append(loss.detach())
         if dp_grads:
             state["grad_scale"] = all_reduce_gradients(opt.params)        # RCCL over xGMI: 59 floats per Gaussian
         state["out"] = out
 
     def barrier():
-        if state["pending"] is not None:
-            state["pending"][0].wait()
-            state["pending"] = None
+        # every rank waits for its own GPU, then for all others: the collective that reduces the mean loss of the steps
+        # since the last barrier is the point every rank has to arrive at (a dist.barrier() behind it would be a second
+        # collective of the same kind inside the timed region)
         torch.cuda.synchronize()
         if use_dist:
-            dist.barrier()
+            mean_loss = torch.stack(state["losses"]).mean() if state["losses"] else torch.zeros((), device=scene.bg.device)
+            state["losses"].clear()
+            dist.all_reduce(mean_loss)
+            state["mean_loss"] = float(mean_loss.item()) / dist.get_world_size()
         torch.cuda.synchronize()
 
     for _ in range(warmup):
@@ -266,6 +268,12 @@ def main():
     if use_dist:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
+        # the communicator is set up by its first collective, which takes seconds, and PyTorch loads a kernel's code
+        # at its first use (tens of milliseconds): here, not in the barrier between the warm-up and the timed steps,
+        # where the GPU would sit idle for that long and start the timed steps at idle clocks
+        z = torch.zeros((), device=dev)
+        dist.all_reduce(torch.stack([z, z]).mean())     # also loads the kernels the barrier's reduction of the losses uses
+        torch.cuda.synchronize()
     if args.gpus != world and rank == 0:
         print(f"warning: --gpus {args.gpus} but WORLD_SIZE {world}", file=sys.stderr)
 
@@ -362,7 +370,7 @@ def main():
                           "ms": round(adam_ms, 4), "parameters": n_params,
                           "GBps": round(28 * n_params / (adam_ms * 1e-3) / 1e9, 1)},
             "gradient_exchange": "all-reduce of all gradients inside the timed step" if args.dp_grads
-                                 else "none (scalar loss only)",
+                                 else "none (the mean loss, one scalar, once per timed region)",
         }
         if world == 1 and args.workload == "c3" and not args.no_variants and not args.unfused:
             line["variants"] = variants(scene, dgr, args, dev)
