@@ -14,6 +14,10 @@ same replicated cloud (camera rotated by rank*45 degrees); the path has no excha
 between the ranks, the mean loss of the timed steps is all-reduced over RCCL once,
 before the closing barrier: per-GPU work is fixed, scaling is weak.
 
+A measurement starts with 40 untimed steps (the W warm-up steps are the last of
+them): a fresh process reaches its steady step time only after some thirty (GPU
+clocks, allocator), and K timed steps right behind five would measure that ramp.
+
 Rank 0 prints ONE JSON line.  `value` is render throughput, Msplats/s = Gaussians
 submitted per second of forward render (preprocess + binning + blend), summed
 over ranks, measured with device events inside the timed training steps;
@@ -59,6 +63,7 @@ WORKLOADS = {
     "c5": (6_000_000, 1920, 1080, 3, 0.5, None),
 }
 
+SETTLE_STEPS = 40                 # untimed steps a measurement starts with, the W warm-up steps included
 DOMINANT_STAGE = "blend_bwd"      # the longest kernel of the step on the headline workload: what the roofline object prices
 
 
@@ -203,6 +208,10 @@ def measure(scene, dgr, fused, steps, warmup, use_dist=False, dp_grads=False, op
             state["mean_loss"] = float(mean_loss.item()) / dist.get_world_size()
         torch.cuda.synchronize()
 
+    # A fresh process takes some forty steps to reach its steady step time (the GPU's clocks ramp up over tens of
+    # milliseconds, the caching allocator settles): those come first, untimed like the W warm-up steps behind them
+    for _ in range(max(0, SETTLE_STEPS - warmup)):
+        step(False)
     for _ in range(warmup):
         step(False)
     barrier()
@@ -341,7 +350,8 @@ def main():
         line = {
             "metric": "train-step ms + render Msplats/s @1080p, 1M Gaussians, 1/2/4/8 MI355X",
             "value": round(msplats, 2), "unit": "Msplats/s", "n_gpus": world, "steps": args.steps,
-            "warmup": args.warmup, "ms_per_step": round(ms_per_step, 3), "higher_is_better": True,
+            "warmup": args.warmup, "untimed_steps_before_the_timed_ones": max(SETTLE_STEPS, args.warmup),
+            "ms_per_step": round(ms_per_step, 3), "higher_is_better": True,
             "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
             "config": {"workload": f"{args.workload}: {P} Gaussians, {W}x{H}, SH degree {deg}, full train step "
                                    "(activations + render + 0.8*L1+0.2*(1-SSIM) + backward), one view per GPU",
