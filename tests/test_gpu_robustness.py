@@ -439,3 +439,49 @@ def test_the_single_call_with_a_pageable_landing_buffer():
     # the pinned way leaves its ticket behind the sizes
     again = _forward(dgr, s, c, single_call=True)
     assert int(kept[0]) == again.num_rendered and int(kept[7]) != 0
+
+
+def test_two_prepared_forwards_alive_at_once_backward_in_reverse_order():
+    """Two forwards with prepared backwards (each with its own block of accumulator, flags and cleared gradients)
+    are alive at the same time and their backwards run in the opposite order, on a stream of their own: every
+    gradient equals the one its scene gives alone, bit for bit where the sums are shared, and the second
+    backward of a state (which finds nothing prepared) still gives the same numbers."""
+    import diff_gaussian_rasterization as dgr
+    scenes = []
+    for seed, (W, H), P in ((51, (384, 216), 40_000), (52, (300, 300), 25_000)):
+        cloud, cam, bg, _ = make_scene(P, W, H, sh_degree=2, seed=seed, coeffs=9)
+        scenes.append((_gpu_settings(cam, bg, 2, 1.0), cloud.to("cuda")))
+
+    def forward(s, c):
+        return dgr.rasterize_forward(s, c.xyz, c.opacity, shs=c.features, scales=c.scaling, rotations=c.rotation,
+                                     single_call=True, prepare_backward=True)
+
+    def backward(s, c, st, d, sums=None):
+        return dgr.rasterize_backward(s, st, d, c.xyz, shs=c.features, scales=c.scaling, rotations=c.rotation, dsplat=sums)
+
+    stream = torch.cuda.Stream()
+    with torch.cuda.stream(stream):
+        states = [forward(s, c) for s, c in scenes]
+        ds = [torch.randn_like(st.color) for st in states]
+        sums = [None, None]
+        grads = [None, None]
+        for k in (1, 0):                                           # reverse order
+            s, c = scenes[k]
+            sums[k] = dgr.blend_backward(states[k], ds[k])
+            grads[k] = backward(s, c, states[k], ds[k], sums[k])
+        again = [backward(scenes[k][0], scenes[k][1], states[k], ds[k], sums[k]) for k in (0, 1)]
+        alone = []
+        for k in (0, 1):
+            s, c = scenes[k]
+            st = dgr.rasterize_forward(s, c.xyz, c.opacity, shs=c.features, scales=c.scaling, rotations=c.rotation,
+                                       single_call=False)
+            assert torch.equal(st.color, states[k].color) and torch.equal(st.point_list, states[k].point_list)
+            alone.append(backward(s, c, st, ds[k], sums[k]))
+    stream.synchronize()
+    for k in (0, 1):
+        for name, v in alone[k].items():
+            if v is None:
+                continue
+            assert torch.equal(grads[k][name], v), (k, name)
+            assert torch.equal(again[k][name], v), (k, name)
+        assert float(alone[k]["means3D"].abs().max()) > 0.0
