@@ -747,6 +747,7 @@ extern "C" int gsr_bin_sort_status(int P, const void* scratch, size_t scratch_by
 }
 
 extern "C" void gsr_debug_sort_spin_limit(uint32_t limit) { gsr::set_sort_spin_limit(limit); }
+extern "C" void gsr_assume_exclusive_device(int on) { gsr::set_exclusive_device(on); }
 
 extern "C" size_t gsr_bin_lists_bytes(uint32_t V, uint32_t E1, uint32_t E2, int W, int H) {
   if (V == 0 || W <= 0 || H <= 0) return 256;

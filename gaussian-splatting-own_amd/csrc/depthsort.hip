@@ -26,8 +26,13 @@
 //
 // Forward progress: a workgroup takes its number from an atomic ticket when it starts running,
 // so every workgroup it waits for is already running or done; the waits are bounded by a spin
-// limit anyway (on overrun the sort sets an error word and still terminates).
+// limit anyway (on overrun the sort sets an error word and still terminates).  A caller that has
+// the GPU to itself (gsr_assume_exclusive_device, or GSR_EXCLUSIVE_DEVICE=1 in the environment)
+// may skip the ticket when the whole grid is resident at once: workgroup b then takes chunk b.
+// That rests on every workgroup of the grid being able to start, which other kernels holding CU
+// slots (a second stream, another process, a CU mask) can break; hence opt-in only.
 #include <atomic>
+#include <cstdlib>
 #include <mutex>
 #include <type_traits>
 
@@ -54,6 +59,20 @@ constexpr int kWindow = 16;                // predecessors inspected per look-ba
 constexpr uint32_t kSpinLimit = 1u << 22;  // look-back steps before giving up (never reached in a healthy run)
 // what the next sorts use; only tests of the give-up path set anything else
 std::atomic<uint32_t> g_spin_limit{kSpinLimit};
+// -1 = not decided yet (the environment is asked at first use), 0 = tickets, 1 = the caller has the GPU to itself
+std::atomic<int> g_exclusive{-1};
+
+bool exclusive_device() {
+  int v = g_exclusive.load(std::memory_order_relaxed);
+  if (v < 0) {
+    const char* e = getenv("GSR_EXCLUSIVE_DEVICE");
+    v = (e && e[0] && !(e[0] == '0' && e[1] == 0)) ? 1 : 0;
+    int expected = -1;
+    g_exclusive.compare_exchange_strong(expected, v, std::memory_order_relaxed);
+    v = g_exclusive.load(std::memory_order_relaxed);
+  }
+  return v == 1;
+}
 
 // control words behind the 4 x 256 histogram bins
 enum { kCtlTicket = 0, kCtlError = 4, kCtlValid = 8, kCtlWords = 16 };   // 4 tickets, the error word, 8 partial key counts
@@ -262,8 +281,12 @@ __global__ void __launch_bounds__(kThreads) sort_pass_kernel(PassArgs a) {
 
   // A pass that follows one in which a look-back gave up would rank keys that were never written
   // against the up-front histograms, and its positions would no longer be bounded by the key count:
-  // the failure is sticky, every later pass of the sort does nothing (one scalar load, uniform).
-  if (PASS > 0 && a.ctl[kCtlError] != 0u) return;
+  // the failure is sticky, every later pass of the sort does nothing (one scalar load, uniform).  Only the
+  // bits of EARLIER passes are looked at: those are final once this kernel runs, so every wave of every
+  // workgroup reads the same answer; a failure raised during this pass by another workgroup goes through
+  // the bounded look-back like any other, and nobody leaves without publishing its counts.
+  constexpr uint32_t kEarlier = ((1u << PASS) - 1u) | (((1u << PASS) - 1u) << 4);
+  if (PASS > 0 && (a.ctl[kCtlError] & kEarlier) != 0u) return;
 
   // One bin of the top byte's histogram holds every key: the last pass would move nothing.  Pass 2 then
   // writes the result itself and pass 3 has nothing to do.  The test reads this pass's view of the
@@ -522,7 +545,8 @@ int depth_sort(int P, const uint32_t* keys, const uint64_t* vals, uint64_t* sort
                      hist, ctl, hist_blocks, sizes_here ? *mirror : no_mirror);
   const dim3 block(kThreads);
   const uint32_t spin_limit = g_spin_limit.load(std::memory_order_relaxed);
-  const uint32_t static_order = L.workgroups <= resident_workgroups(items_per_thread((uint32_t)P)) ? 1u : 0u;
+  const uint32_t static_order =
+      exclusive_device() && L.workgroups <= resident_workgroups(items_per_thread((uint32_t)P)) ? 1u : 0u;
   const size_t per_pass = L.state_words + L.group_words;
   auto args = [&](int pass, const uint32_t* kin, const u64* vin, uint32_t* kout, u64* vout) {
     uint32_t* s = states + pass * per_pass;
@@ -570,6 +594,8 @@ const uint32_t* depth_sort_error_word(const void* scratch) { return (const uint3
 
 void set_sort_spin_limit(uint32_t limit) { g_spin_limit.store(limit ? limit : kSpinLimit, std::memory_order_relaxed); }
 
+void set_exclusive_device(int on) { g_exclusive.store(on ? 1 : 0, std::memory_order_relaxed); }
+
 }  // namespace gsr
 
 // ---------------------------------------------------------------------------
@@ -610,19 +636,31 @@ int static_scratch(void** out) {
 
 }  // namespace
 
+// What the sort's layout asks for at the capacity, and what the array holds (a test ties the two together).
+extern "C" size_t gsr_bin_sort_static_bytes(int which) {
+  return which == 0 ? kStaticBytes : layout((uint32_t)kStaticMaxKeys).total;
+}
+
 extern "C" int gsr_bin_sort_static(int P, const uint32_t* depth_keys, const uint64_t* sort_vals, uint64_t* sorted_vals,
                                    const uint32_t** error_word, void* stream) {
   GSR_REQUIRE(P >= 0, "bin_sort_static: bad P");
   if (P > kStaticMaxKeys)
     return gsr::fail(GSR_E_TOO_LARGE, "bin_sort_static: %d keys exceed the static scratch's capacity of %d; use gsr_bin_sort "
                      "with caller memory", P, kStaticMaxKeys);
-  if (layout((uint32_t)kStaticMaxKeys).total > kStaticBytes)
-    return gsr::fail(GSR_E_SCRATCH, "bin_sort_static: the static scratch (%zu bytes) is smaller than the sort's layout (%zu)",
-                     kStaticBytes, layout((uint32_t)kStaticMaxKeys).total);
+  // the layout of THIS key count (keys per thread change with it, so the size is not monotonic by construction)
+  if (layout((uint32_t)P).total > kStaticBytes)
+    return gsr::fail(GSR_E_SCRATCH, "bin_sort_static: the static scratch (%zu bytes) is smaller than the sort's layout for %d keys (%zu)",
+                     kStaticBytes, P, layout((uint32_t)P).total);
   void* ptr = nullptr;
   int rc = static_scratch(&ptr);
   if (rc) return rc;
   if (error_word) *error_word = gsr::depth_sort_error_word(ptr);
+  // everything a later call looks up once per device is looked up now, so that a P = 0 call warms the device up
+  if (exclusive_device()) {
+    (void)resident_workgroups(kTinyItems);
+    (void)resident_workgroups(kFewItems);
+    (void)resident_workgroups(kManyItems);
+  }
   if (P == 0) return GSR_OK;
   GSR_REQUIRE(depth_keys && sort_vals && sorted_vals, "bin_sort_static: null pointer");
   // depth_sort clears the look-back words, tickets, histograms and the error word with a kernel of its own

@@ -128,18 +128,16 @@ extern "C" int gsr_forward(const GsrForwardArgs* a, gsr_resize_fn resize, void* 
     static const bool sort_clears = getenv("GSR_SORT_CLEARS_ITSELF") != nullptr;   // for measurements of the difference
     gsr::PreprocessExtras extras{landing != nullptr, nullptr, 0};
     if (!sort_clears) gsr::depth_sort_clear_region(P, w.sort_scratch, &extras.clear_at, &extras.clear_words);
-    gsr::preprocess_extras(&extras);
     if (a->raw)
-      rc = gsr_preprocess_fwd_raw(P, a->D, a->M - 1, a->means3D, a->scales, a->scale_modifier, a->rotations, a->opacities,
+      rc = gsr::preprocess_fwd_raw(extras, P, a->D, a->M - 1, a->means3D, a->scales, a->scale_modifier, a->rotations, a->opacities,
                                   a->shs, a->shs_rest, a->viewmatrix, a->projmatrix, a->campos, W, H, a->tanfovx,
                                   a->tanfovy, a->reference_lists, w.records, a->radii, nullptr, w.depth_keys, nullptr,
                                   w.sort_vals, w.totals, a->status, a->visible, stream);
     else
-      rc = gsr_preprocess_fwd(P, a->D, a->M, a->means3D, a->scales, a->scale_modifier, a->rotations, a->opacities, a->shs,
+      rc = gsr::preprocess_fwd(extras, P, a->D, a->M, a->means3D, a->scales, a->scale_modifier, a->rotations, a->opacities, a->shs,
                               a->colors_precomp, a->cov3D_precomp, a->viewmatrix, a->projmatrix, a->campos, W, H,
                               a->tanfovx, a->tanfovy, a->prefiltered, a->reference_lists, w.records, a->radii, nullptr,
                               w.depth_keys, nullptr, w.sort_vals, w.totals, a->status, a->visible, stream);
-    gsr::preprocess_extras(nullptr);
     if (rc) return rc;
     if ((rc = checkpoint("preprocess"))) return rc;
     if (a->after_preprocess) a->after_preprocess(a->hook_ctx);

@@ -102,7 +102,7 @@ __device__ __forceinline__ uint32_t sum_totals(int blocks, const uint32_t* __res
 // The same as a kernel of one workgroup; defined with the binning kernels.
 int launch_totals_final(int blocks, const uint32_t* partials, const uint32_t* status, uint32_t* totals,
                         hipStream_t stream);
-// What gsr_forward asks of the gsr_preprocess_fwd[_raw] it calls (same thread, set around the call; null = nothing):
+// What gsr_forward asks of the preprocess beyond gsr_preprocess_fwd[_raw]'s own arguments:
 // defer_totals: leave the partial records of the list sizes unsummed (P > 0), the depth sort's first kernel sums
 // them; clear_at / clear_words: memory the kernel's workgroups clear as their last act (the depth sort's histograms
 // and look-back states, which then needs no clearing kernel of its own).  Defined with the preprocess kernels,
@@ -112,7 +112,20 @@ struct PreprocessExtras {
   uint32_t* clear_at;
   size_t clear_words;
 };
-void preprocess_extras(const PreprocessExtras* extras);
+// gsr_preprocess_fwd / gsr_preprocess_fwd_raw with the extras as an explicit argument (the C entry points pass none).
+int preprocess_fwd(const PreprocessExtras& extras, int P, int D, int M, const float* means3D, const float* scales,
+                   float scale_modifier, const float* rotations, const float* opacities, const float* shs,
+                   const float* colors_precomp, const float* cov3D_precomp, const float* viewmatrix,
+                   const float* projmatrix, const float* campos, int W, int H, float tanfovx, float tanfovy,
+                   int prefiltered, int reference_lists, uint32_t* records, int32_t* radii, uint32_t* tiles_touched,
+                   uint32_t* depth_keys, uint32_t* rects, uint64_t* sort_vals, uint32_t* totals, const uint32_t* status,
+                   uint8_t* visible, void* stream);
+int preprocess_fwd_raw(const PreprocessExtras& extras, int P, int D, int n_rest, const float* xyz, const float* scaling_raw,
+                       float scale_modifier, const float* rotation_raw, const float* opacity_raw, const float* features_dc,
+                       const float* features_rest, const float* viewmatrix, const float* projmatrix, const float* campos,
+                       int W, int H, float tanfovx, float tanfovy, int reference_lists, uint32_t* records, int32_t* radii,
+                       uint32_t* tiles_touched, uint32_t* depth_keys, uint32_t* rects, uint64_t* sort_vals, uint32_t* totals,
+                       const uint32_t* status, uint8_t* visible, void* stream);
 int totals_partial_blocks(int P);
 const uint32_t* totals_partials(const uint32_t* totals);
 
@@ -145,6 +158,8 @@ int depth_sort_status(const void* scratch, hipStream_t stream);
 const uint32_t* depth_sort_error_word(const void* scratch);
 // Look-back steps a workgroup waits before it gives up (0 = the default); for tests of that path.
 void set_sort_spin_limit(uint32_t limit);
+// The caller has the GPU to itself: sorts may skip the per-workgroup ticket (see depthsort.hip).
+void set_exclusive_device(int on);
 
 // gsr_blend_fwd_timed with a zero-fill: every workgroup clears an equal share of it as its last act.
 int blend_fwd(int W, int H, const uint32_t* ranges, const uint32_t* point_list, const uint32_t* records, const float* bg,

@@ -795,18 +795,13 @@ int launch_sparse_bwd(int degree, const BwdArgs& a, hipStream_t st) {
 constexpr int kTotalsHead = 8;   // N, E1, E2, V, status, 3 spare words; the per-block partial sums follow
 extern "C" size_t gsr_totals_words(int P) { return kTotalsHead + 4 * (size_t)(P > 0 ? gsr::div_up(P, kBlock) : 0); }
 
-namespace {
-// Set by gsr_forward around its call of the preprocess (same thread).
-thread_local gsr::PreprocessExtras t_extras{false, nullptr, 0};
-}  // namespace
-
-void gsr::preprocess_extras(const PreprocessExtras* extras) { t_extras = extras ? *extras : PreprocessExtras{false, nullptr, 0}; }
 int gsr::totals_partial_blocks(int P) { return P > 0 ? gsr::div_up(P, kBlock) : 0; }
 const uint32_t* gsr::totals_partials(const uint32_t* totals) { return totals + kTotalsHead; }
 
 namespace {
 
-int launch_preprocess_fwd(const char* who, FwdArgs a, int D, uint32_t* totals, const uint32_t* status, void* stream) {
+int launch_preprocess_fwd(const char* who, FwdArgs a, int D, uint32_t* totals, const uint32_t* status, bool defer_totals,
+                          void* stream) {
   hipStream_t st = (hipStream_t)stream;
   const int blocks = gsr::div_up(a.P, kBlock);
   dim3 grid(blocks), block(kBlock);
@@ -818,20 +813,20 @@ int launch_preprocess_fwd(const char* who, FwdArgs a, int D, uint32_t* totals, c
     default: hipLaunchKernelGGL(preprocess_fwd_kernel<3>, grid, block, 0, st, a); break;
   }
   int rc = gsr::check_launch(who);
-  if (rc || t_extras.defer_totals) return rc;
+  if (rc || defer_totals) return rc;
   return gsr::launch_totals_final(blocks, totals + kTotalsHead, status, totals, st);
 }
 
 }  // namespace
 
-extern "C" int gsr_preprocess_fwd(int P, int D, int M, const float* means3D, const float* scales,
-                                  float scale_modifier, const float* rotations, const float* opacities,
-                                  const float* shs, const float* colors_precomp, const float* cov3D_precomp,
-                                  const float* viewmatrix, const float* projmatrix, const float* campos,
-                                  int W, int H, float tanfovx, float tanfovy, int prefiltered, int reference_lists,
-                                  uint32_t* records, int32_t* radii, uint32_t* tiles_touched,
-                                  uint32_t* depth_keys, uint32_t* rects, uint64_t* sort_vals, uint32_t* totals,
-                                  const uint32_t* status, uint8_t* visible, void* stream) {
+int gsr::preprocess_fwd(const PreprocessExtras& extras, int P, int D, int M, const float* means3D, const float* scales,
+                        float scale_modifier, const float* rotations, const float* opacities,
+                        const float* shs, const float* colors_precomp, const float* cov3D_precomp,
+                        const float* viewmatrix, const float* projmatrix, const float* campos,
+                        int W, int H, float tanfovx, float tanfovy, int prefiltered, int reference_lists,
+                        uint32_t* records, int32_t* radii, uint32_t* tiles_touched,
+                        uint32_t* depth_keys, uint32_t* rects, uint64_t* sort_vals, uint32_t* totals,
+                        const uint32_t* status, uint8_t* visible, void* stream) {
   (void)prefiltered;
   GSR_REQUIRE(P >= 0 && W > 0 && H > 0, "preprocess_fwd: bad sizes P=%d W=%d H=%d", P, W, H);
   GSR_REQUIRE(totals && ((uintptr_t)totals & 15) == 0, "preprocess_fwd: totals must be non-null and 16-byte aligned");
@@ -846,10 +841,24 @@ extern "C" int gsr_preprocess_fwd(int P, int D, int M, const float* means3D, con
   GSR_REQUIRE(W <= 16 * 16 * 255 && H <= 16 * 16 * 255, "preprocess_fwd: image %dx%d too large", W, H);
   const gsr::Pack pack = gsr::make_pack(P, gsr::div_up(W, GSR_TILE_X), gsr::div_up(H, GSR_TILE_Y));
   GSR_REQUIRE(pack.bits() <= 64, "preprocess_fwd: %d Gaussians on a %dx%d image do not fit the 64-bit sort value", P, W, H);
-  FwdArgs a{t_extras.clear_at, t_extras.clear_words, 0, 0, reference_lists, P, M, W, H, means3D, scales, rotations, opacities, shs, nullptr, colors_precomp, cov3D_precomp,
+  FwdArgs a{extras.clear_at, extras.clear_words, 0, 0, reference_lists, P, M, W, H, means3D, scales, rotations, opacities, shs, nullptr, colors_precomp, cov3D_precomp,
             viewmatrix, projmatrix, campos, scale_modifier, tanfovx, tanfovy, pack, records, radii, tiles_touched,
             depth_keys, rects, (unsigned long long*)sort_vals, nullptr, visible};
-  return launch_preprocess_fwd("preprocess_fwd", a, D, totals, status, stream);
+  return launch_preprocess_fwd("preprocess_fwd", a, D, totals, status, extras.defer_totals, stream);
+}
+
+extern "C" int gsr_preprocess_fwd(int P, int D, int M, const float* means3D, const float* scales,
+                                  float scale_modifier, const float* rotations, const float* opacities,
+                                  const float* shs, const float* colors_precomp, const float* cov3D_precomp,
+                                  const float* viewmatrix, const float* projmatrix, const float* campos,
+                                  int W, int H, float tanfovx, float tanfovy, int prefiltered, int reference_lists,
+                                  uint32_t* records, int32_t* radii, uint32_t* tiles_touched,
+                                  uint32_t* depth_keys, uint32_t* rects, uint64_t* sort_vals, uint32_t* totals,
+                                  const uint32_t* status, uint8_t* visible, void* stream) {
+  return gsr::preprocess_fwd(gsr::PreprocessExtras{false, nullptr, 0}, P, D, M, means3D, scales, scale_modifier, rotations,
+                             opacities, shs, colors_precomp, cov3D_precomp, viewmatrix, projmatrix, campos, W, H, tanfovx,
+                             tanfovy, prefiltered, reference_lists, records, radii, tiles_touched, depth_keys, rects,
+                             sort_vals, totals, status, visible, stream);
 }
 
 extern "C" int gsr_mark_visible(int P, const float* means3D, const float* viewmatrix, uint8_t* present,
@@ -908,15 +917,14 @@ extern "C" int gsr_preprocess_bwd(int P, int D, int M, const float* means3D, con
 // per call at 1M Gaussians, and as many again in backward) folded into the
 // per-Gaussian kernels.  Same kernels, `raw` switches the loads and the chain rule.
 // ---------------------------------------------------------------------------
-extern "C" int gsr_preprocess_fwd_raw(int P, int D, int n_rest, const float* xyz, const float* scaling_raw,
-                                      float scale_modifier, const float* rotation_raw, const float* opacity_raw,
-                                      const float* features_dc, const float* features_rest,
-                                      const float* viewmatrix, const float* projmatrix, const float* campos, int W,
-                                      int H, float tanfovx, float tanfovy, int reference_lists, uint32_t* records,
-                                      int32_t* radii,
-                                      uint32_t* tiles_touched, uint32_t* depth_keys, uint32_t* rects,
-                                      uint64_t* sort_vals, uint32_t* totals, const uint32_t* status,
-                                      uint8_t* visible, void* stream) {
+int gsr::preprocess_fwd_raw(const PreprocessExtras& extras, int P, int D, int n_rest, const float* xyz,
+                            const float* scaling_raw, float scale_modifier, const float* rotation_raw,
+                            const float* opacity_raw, const float* features_dc, const float* features_rest,
+                            const float* viewmatrix, const float* projmatrix, const float* campos, int W,
+                            int H, float tanfovx, float tanfovy, int reference_lists, uint32_t* records,
+                            int32_t* radii, uint32_t* tiles_touched, uint32_t* depth_keys, uint32_t* rects,
+                            uint64_t* sort_vals, uint32_t* totals, const uint32_t* status,
+                            uint8_t* visible, void* stream) {
   GSR_REQUIRE(P >= 0 && W > 0 && H > 0, "preprocess_fwd_raw: bad sizes P=%d W=%d H=%d", P, W, H);
   GSR_REQUIRE(totals && ((uintptr_t)totals & 15) == 0, "preprocess_fwd_raw: totals must be non-null and 16-byte aligned");
   if (P == 0) return gsr::launch_totals_final(0, totals + kTotalsHead, status, totals, (hipStream_t)stream);
@@ -931,11 +939,26 @@ extern "C" int gsr_preprocess_fwd_raw(int P, int D, int n_rest, const float* xyz
   GSR_REQUIRE(pack.bits() <= 64, "preprocess_fwd_raw: %d Gaussians on a %dx%d image do not fit the 64-bit sort value", P,
               W, H);
   // with no rest tensor the dc tensor alone is a (P,1,3) shs tensor
-  FwdArgs a{t_extras.clear_at, t_extras.clear_words, 1, n_rest, reference_lists, P, 1 + n_rest, W, H, xyz, scaling_raw, rotation_raw, opacity_raw, features_dc,
+  FwdArgs a{extras.clear_at, extras.clear_words, 1, n_rest, reference_lists, P, 1 + n_rest, W, H, xyz, scaling_raw, rotation_raw, opacity_raw, features_dc,
             n_rest > 0 ? features_rest : nullptr, nullptr, nullptr, viewmatrix, projmatrix, campos, scale_modifier,
             tanfovx, tanfovy, pack, records, radii, tiles_touched, depth_keys, rects, (unsigned long long*)sort_vals,
             nullptr, visible};
-  return launch_preprocess_fwd("preprocess_fwd_raw", a, D, totals, status, stream);
+  return launch_preprocess_fwd("preprocess_fwd_raw", a, D, totals, status, extras.defer_totals, stream);
+}
+
+extern "C" int gsr_preprocess_fwd_raw(int P, int D, int n_rest, const float* xyz, const float* scaling_raw,
+                                      float scale_modifier, const float* rotation_raw, const float* opacity_raw,
+                                      const float* features_dc, const float* features_rest,
+                                      const float* viewmatrix, const float* projmatrix, const float* campos, int W,
+                                      int H, float tanfovx, float tanfovy, int reference_lists, uint32_t* records,
+                                      int32_t* radii,
+                                      uint32_t* tiles_touched, uint32_t* depth_keys, uint32_t* rects,
+                                      uint64_t* sort_vals, uint32_t* totals, const uint32_t* status,
+                                      uint8_t* visible, void* stream) {
+  return gsr::preprocess_fwd_raw(gsr::PreprocessExtras{false, nullptr, 0}, P, D, n_rest, xyz, scaling_raw, scale_modifier,
+                                 rotation_raw, opacity_raw, features_dc, features_rest, viewmatrix, projmatrix, campos, W, H,
+                                 tanfovx, tanfovy, reference_lists, records, radii, tiles_touched, depth_keys, rects,
+                                 sort_vals, totals, status, visible, stream);
 }
 
 extern "C" int gsr_preprocess_bwd_raw(int P, int D, int n_rest, const float* xyz, const float* scaling_raw,

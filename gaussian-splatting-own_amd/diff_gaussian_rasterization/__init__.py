@@ -108,6 +108,8 @@ def _load():
     lib.gsr_bin_sort_status.argtypes = [ci, vp, C.c_size_t, vp]
     lib.gsr_debug_sort_spin_limit.argtypes = [u32]
     lib.gsr_debug_sort_spin_limit.restype = None
+    lib.gsr_assume_exclusive_device.argtypes = [ci]
+    lib.gsr_assume_exclusive_device.restype = None
     lib.gsr_bin_sort_error_word.argtypes = [vp]
     lib.gsr_bin_sort_error_word.restype = vp
     lib.gsr_bin_lists.argtypes = [ci, u32, u32, u32, u32, ci, ci, vp, vp, vp, vp, vp, vp, vp, vp, C.c_size_t, vp]
@@ -133,6 +135,13 @@ def _load():
 
 
 _lib = _load()
+
+
+def assume_exclusive_device(on: bool = True) -> None:
+    """Tells the library that this process has the GPU to itself (no other process, no second stream with
+    kernels of its own): the depth sort may then skip its per-workgroup tickets when its whole grid is resident
+    at once.  Off by default; GSR_EXCLUSIVE_DEVICE=1 in the environment sets it too."""
+    _lib.gsr_assume_exclusive_device(int(bool(on)))
 
 
 class StageTimer:

@@ -9,8 +9,8 @@ point cloud with the 3-nearest-neighbour scales (``:124-147``), the
 densification statistics fed by the rasterizer's screen-space gradient
 (``:405-407``, ``train.py:113-116``), the PLY model file (``:191-256``), and the
 host bookkeeping that changes the number of Gaussians between steps
-(``:120-122, 179-189, 291-403``: SH degree ramp, opacity reset, clone / split /
-prune) with the checkpoint tuple (``:61-93``), all on top of ``GaussianAdam``'s
+(``:120-122, 179-189, 291-403``: SH degree ramp, opacity reset, and the clone / split /
+prune refinement as one pass) with the checkpoint tuple (``:61-93``), all on top of ``GaussianAdam``'s
 state surgery.  These are plain PyTorch tensor operations, as in the reference.
 """
 from __future__ import annotations
@@ -138,44 +138,54 @@ class GaussianParams(nn.Module):
         self.max_radii2D = torch.zeros((n,), device=dev)
 
     @torch.no_grad()
-    def densify_and_split(self, grads, grad_threshold, scene_extent, N: int = 2, generator=None) -> None:
-        """:349-372: large Gaussians with a large screen-space gradient become N smaller ones, sampled
-        from the Gaussian itself (scales divided by 0.8 N); the original goes."""
-        n_init, dev = self._xyz.shape[0], self._xyz.device
-        padded = torch.zeros((n_init,), device=dev)
-        padded[:grads.shape[0]] = grads.squeeze()
-        sel = (padded >= grad_threshold) & (self.get_scaling.max(dim=1).values > self.percent_dense * scene_extent)
-        stds = self.get_scaling[sel].repeat(N, 1)
-        samples = torch.normal(mean=torch.zeros_like(stds), std=stds, generator=generator)
-        rots = quaternion_to_matrix(self._rotation[sel]).repeat(N, 1, 1)
-        new_xyz = torch.bmm(rots, samples.unsqueeze(-1)).squeeze(-1) + self._xyz[sel].repeat(N, 1)
-        new_scaling = torch.log(self.get_scaling[sel].repeat(N, 1) / (0.8 * N))
-        self.densification_postfix(new_xyz, self._features_dc[sel].repeat(N, 1, 1),
-                                   self._features_rest[sel].repeat(N, 1, 1), self._opacity[sel].repeat(N, 1),
-                                   new_scaling, self._rotation[sel].repeat(N, 1))
-        self.prune_points(torch.cat((sel, torch.zeros((N * int(sel.sum()),), device=dev, dtype=torch.bool))))
+    def densify_and_prune(self, max_grad, min_opacity, extent, max_screen_size, generator=None, children: int = 2) -> None:
+        """The refinement step train.py:118-120 runs every 100 iterations, with the rules of
+        scene/gaussian_model.py:349-403 applied in one pass over the current Gaussians:
 
-    @torch.no_grad()
-    def densify_and_clone(self, grads, grad_threshold, scene_extent) -> None:
-        """:374-387: small Gaussians with a large screen-space gradient are duplicated in place."""
-        sel = (torch.norm(grads, dim=-1) >= grad_threshold) & \
-              (self.get_scaling.max(dim=1).values <= self.percent_dense * scene_extent)
-        self.densification_postfix(self._xyz[sel], self._features_dc[sel], self._features_rest[sel], self._opacity[sel],
-                                   self._scaling[sel], self._rotation[sel])
+        * a Gaussian is *restless* when its mean screen-space gradient norm (accumulated norm / times seen, 0 for
+          one never seen) reaches ``max_grad``;
+        * restless and small (largest scale <= percent_dense * extent): a copy of it is appended;
+        * restless and large: ``children`` Gaussians are appended, centred on points drawn from the parent's
+          own distribution, with the parent's scales divided by 0.8 * children, and the parent is removed;
+        * finally everything with opacity below ``min_opacity`` goes (copies and children included), and, when
+          ``max_screen_size`` is given, everything larger than a tenth of the scene or whose recorded screen
+          radius exceeds it.  Appending resets the statistics of every Gaussian, so after an append the recorded
+          radii are zero.
 
-    @torch.no_grad()
-    def densify_and_prune(self, max_grad, min_opacity, extent, max_screen_size, generator=None) -> None:
-        """:389-403 (train.py:118-120 calls it every 100 iterations)."""
-        grads = self.xyz_gradient_accum / self.denom
-        grads[grads.isnan()] = 0.0
-        self.densify_and_clone(grads, max_grad, extent)
-        self.densify_and_split(grads, max_grad, extent, generator=generator)
-        prune_mask = (self.get_opacity < min_opacity).squeeze()
+        Resulting order: the kept originals, the copies, the children (all first children, then all second ones);
+        new Gaussians start with zero optimiser moments."""
+        dev, count = self._xyz.device, self._xyz.shape[0]
+        ratio = (self.xyz_gradient_accum / self.denom).reshape(-1)
+        restless = torch.where(ratio.isnan(), torch.zeros_like(ratio), ratio) >= max_grad     # 0 / 0 (never seen) counts as 0
+        scale = self.get_scaling
+        large = scale.amax(dim=1) > self.percent_dense * extent
+        copy_idx = torch.nonzero(restless & ~large).reshape(-1)
+        parent_idx = torch.nonzero(restless & large).reshape(-1)
+        family = parent_idx.repeat(children)                       # p0 p1 ... p0 p1 ...
+
+        # children: offsets drawn in the parent's own frame, rotated into the world
+        spread = scale[family]
+        offsets = torch.randn(spread.shape, generator=generator, device=generator.device if generator else dev).to(dev) * spread
+        world = torch.einsum("nij,nj->ni", quaternion_to_matrix(self._rotation[family]), offsets)
+        born = {"xyz": torch.cat((self._xyz[copy_idx], self._xyz[family] + world)),
+                "scaling": torch.cat((self._scaling[copy_idx], torch.log(spread / (0.8 * children))))}
+        for group, attr in self.GROUPS:
+            if group not in born:
+                t = getattr(self, attr)
+                born[group] = torch.cat((t[copy_idx], t[family]))
+        appended = copy_idx.numel() + family.numel()
+        if appended:
+            self.densification_postfix(born["xyz"], born["f_dc"], born["f_rest"], born["opacity"], born["scaling"],
+                                       born["rotation"])
+
+        total = count + appended
+        gone = torch.zeros((total,), dtype=torch.bool, device=dev)
+        gone[parent_idx] = True
+        gone |= self.get_opacity.reshape(-1) < min_opacity
         if max_screen_size:
-            big_points_vs = self.max_radii2D > max_screen_size
-            big_points_ws = self.get_scaling.max(dim=1).values > 0.1 * extent
-            prune_mask = prune_mask | big_points_vs | big_points_ws
-        self.prune_points(prune_mask)
+            gone |= self.get_scaling.amax(dim=1) > 0.1 * extent
+            gone |= self.max_radii2D > max_screen_size          # zeros after an append, as in the reference
+        self.prune_points(gone)
 
     def capture(self):
         """The checkpoint tuple of :61-75, the optimiser's state in torch.optim.Adam's layout."""

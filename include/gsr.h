@@ -22,8 +22,8 @@
  *  - The library keeps no state between calls and every entry point may be
  *    called from several host threads at once, each on its own stream, as long
  *    as no two calls in flight share an output, scratch or status buffer.  The
- *    one exception is the patience setting of gsr_debug_sort_spin_limit (a test
- *    hook, process-wide).
+ *    exceptions are two process-wide settings: the patience of
+ *    gsr_debug_sort_spin_limit (a test hook) and gsr_assume_exclusive_device.
  *  - `stream` is a hipStream_t passed as void* (NULL = the null stream).
  *    Calls only enqueue work; none synchronises.  The one host read-back the
  *    pipeline needs (the list sizes, after gsr_preprocess_fwd) is done by the
@@ -183,13 +183,29 @@ int gsr_bin_sort_status(int P, const void* scratch, size_t scratch_bytes, void* 
 const uint32_t* gsr_bin_sort_error_word(const void* sort_scratch);
 void gsr_debug_sort_spin_limit(uint32_t limit);
 
+/* gsr_assume_exclusive_device(1): the caller asserts that nothing else runs on the GPU while
+ * its sorts do (no other process, no second stream with kernels of its own, no CU mask).  A
+ * sort whose whole grid is resident at once then gives workgroup b chunk b instead of drawing
+ * a ticket per workgroup (1.5 us less per pass at a million keys).  Without the assertion
+ * (the default; also GSR_EXCLUSIVE_DEVICE=1 in the environment at first use sets it) every
+ * workgroup draws a ticket when it starts running, so a workgroup only ever waits for
+ * workgroups that are running or done, whatever else occupies the GPU.  Process-wide; has no
+ * counterpart in the reference (its sort is a library call without cross-workgroup waits). */
+void gsr_assume_exclusive_device(int on);
+
 /* gsr_bin_sort_static: gsr_bin_sort for callers that cannot allocate device memory or have
  * none to hand in (code under HIP graph capture, tight serving loops, harnesses that forbid
  * hipMalloc).  It has no counterpart in the reference.  The sort's scratch is a 26,312,960-byte
  * device array inside the library (every GPU the library runs on holds its own copy until the
  * process ends), so P is limited to GSR_BIN_SORT_STATIC_MAX = 2^20 keys: more is refused with
  * GSR_E_TOO_LARGE.  The call allocates nothing (no hipMalloc / hipFree, no allocating library
- * routine), on any call; it only enqueues kernels on `stream`, whose device must be current.
+ * routine); it only enqueues kernels on `stream`, whose device must be current.
+ * The FIRST call on each device also looks up the array's address and the kernels' occupancy
+ * (which may load the code object and materialise the array): make that call, with P = 0 if
+ * there is nothing to sort yet, outside graph capture or any other section that forbids
+ * allocation; every later call on that device does neither.
+ * gsr_bin_sort_static_bytes(0) = the array's size, (1) = what the sort's layout needs at
+ * GSR_BIN_SORT_STATIC_MAX keys (never more than the former).
  * Same result as gsr_bin_sort, bit for bit.  *error_word (optional out, may be NULL) receives the
  * device address of the sort's error word, for gsr_bin_lists' sort_error argument.
  * All calls on one GPU share that GPU's array: calls that overlap in time on one GPU (two streams,
@@ -198,6 +214,7 @@ void gsr_debug_sort_spin_limit(uint32_t limit);
 #define GSR_BIN_SORT_STATIC_MAX (1 << 20)
 int gsr_bin_sort_static(int P, const uint32_t* depth_keys, const uint64_t* sort_vals,
                         uint64_t* sorted_vals, const uint32_t** error_word, void* stream);
+size_t gsr_bin_sort_static_bytes(int which);
 
 /* gsr_bin_lists: point_list (N) uint32 = Gaussian index per sorted instance;
  * ranges (tiles,2) uint32 = [start,end) into point_list per tile, (0,0) for

@@ -138,3 +138,23 @@ def test_the_backward_block_is_laid_out_as_the_library_expects():
         block.zero_()
         views[next(iter(views))].fill_(1.0)
         assert float(dsplat.abs().max()) == 0.0 and int(touched.max()) == 0
+
+
+def test_static_sort_scratch_is_as_large_as_the_layout_at_its_capacity():
+    """The device array behind gsr_bin_sort_static is declared with a literal size; the sort's layout at the
+    capacity (and at the key counts where the keys per thread change) must fit it."""
+    lib = ctypes.CDLL(LIB)
+    lib.gsr_bin_sort_static_bytes.restype = ctypes.c_size_t
+    lib.gsr_bin_sort_bytes.restype = ctypes.c_size_t
+    have, need = lib.gsr_bin_sort_static_bytes(0), lib.gsr_bin_sort_static_bytes(1)
+    assert need <= have and have - need < 4096                     # no slack to speak of either
+    assert need == lib.gsr_bin_sort_bytes(1 << 20)
+    for p in (1, 4096, 199_999, 200_000, 200_001, 999_999, 1 << 20):
+        assert lib.gsr_bin_sort_bytes(p) <= have, p
+
+
+def test_exclusive_device_switch_is_exported_and_callable_without_a_gpu():
+    lib = ctypes.CDLL(LIB)
+    lib.gsr_assume_exclusive_device.restype = None
+    lib.gsr_assume_exclusive_device(1)
+    lib.gsr_assume_exclusive_device(0)
