@@ -69,9 +69,15 @@ class Oracle:
     """One precision of the oracle.  ``Oracle(np.float32)`` is the parity
     oracle, ``Oracle(np.float64)`` the gradient-check build."""
 
-    def __init__(self, dtype=np.float32, threads: int | None = None):
+    def __init__(self, dtype=np.float32, threads: int | None = None, kernel_order: bool = False):
+        """``kernel_order`` (fp32 only): the build that evaluates the Gaussian's exponent in the HIP blend
+        kernels' operation order (log2 domain, fused multiply-adds) instead of the published expression's; it
+        exists to attribute the difference between the two roundings, the default build stays the oracle."""
         self.dtype = np.dtype(dtype)
-        name = "liboracle_f32.so" if self.dtype == np.float32 else "liboracle_f64.so"
+        if kernel_order and self.dtype != np.float32:
+            raise ValueError("the kernel-order build exists in fp32 only")
+        self.kernel_order = bool(kernel_order)
+        name = ("liboracle_f32k.so" if kernel_order else "liboracle_f32.so") if self.dtype == np.float32 else "liboracle_f64.so"
         path = os.path.join(_BUILD, name)
         if not os.path.exists(path):
             build()
@@ -80,6 +86,7 @@ class Oracle:
         self.lib = C.CDLL(path)
         self.real = C.c_float if self.dtype == np.float32 else C.c_double
         assert self.lib.gso_real_bytes() == self.dtype.itemsize
+        assert self.lib.gso_kernel_order() == int(self.kernel_order)
         self.Cam = _cam_struct(self.real)
         self.lib.gso_bin.restype = C.c_int
 

@@ -42,6 +42,8 @@
 static inline REAL r_sqrt(REAL x) { return sizeof(REAL) == 4 ? (REAL)sqrtf((float)x) : (REAL)sqrt((double)x); }
 static inline REAL r_exp(REAL x) { return sizeof(REAL) == 4 ? (REAL)expf((float)x) : (REAL)exp((double)x); }
 static inline REAL r_ceil(REAL x) { return sizeof(REAL) == 4 ? (REAL)ceilf((float)x) : (REAL)ceil((double)x); }
+static inline REAL r_exp2(REAL x) { return sizeof(REAL) == 4 ? (REAL)exp2f((float)x) : (REAL)exp2((double)x); }
+static inline REAL r_fma(REAL a, REAL b, REAL c) { return sizeof(REAL) == 4 ? (REAL)fmaf((float)a, (float)b, (float)c) : (REAL)fma((double)a, (double)b, (double)c); }
 static inline REAL r_min(REAL a, REAL b) { return a < b ? a : b; }
 static inline REAL r_max(REAL a, REAL b) { return a > b ? a : b; }
 static inline REAL r_abs(REAL a) { return a < 0 ? -a : a; }
@@ -62,6 +64,38 @@ typedef struct {
 } gso_cam;
 
 int gso_real_bytes(void) { return (int)sizeof(REAL); }
+
+/* The Gaussian's exponent and value at offset (dx, dy) from its centre.
+ * Default build: the expression as the published algorithm writes it,
+ * power = -1/2 (A dx^2 + C dy^2) - B dx dy, one IEEE operation after the other,
+ * G = exp(power).
+ * GSO_KERNEL_ORDER build (a second fp32 oracle, used to show that what separates
+ * the HIP blend kernels from the default oracle on ill-conditioned conics is the
+ * rounding of this one expression and nothing else): the sequence of the HIP
+ * kernels' gauss_exponent(), i.e. the conic pre-scaled into the log2 domain,
+ * (la, lb, lc) = (-log2e/2 A, -log2e B, -log2e/2 C) each rounded once, then
+ * p2 = fma(lb dx, dy, fma(la dx, dx, (lc dy) dy)) and G = exp2(p2).
+ * Returns G; *power receives the exponent in the natural-log domain (its sign is
+ * the skip test, its size feeds the margin estimate). */
+int gso_kernel_order(void) {
+#ifdef GSO_KERNEL_ORDER
+  return 1;
+#else
+  return 0;
+#endif
+}
+static inline REAL gauss_value(REAL A, REAL B, REAL Cc, REAL dx, REAL dy, REAL* power) {
+#ifdef GSO_KERNEL_ORDER
+  const REAL log2e = K(1.4426950408889634);
+  const REAL la = (K(-0.5) * log2e) * A, lb = (-log2e) * B, lc = (K(-0.5) * log2e) * Cc;
+  const REAL p2 = r_fma(lb * dx, dy, r_fma(la * dx, dx, (lc * dy) * dy));
+  *power = p2 * K(0.6931471805599453);
+  return r_exp2(p2);
+#else
+  *power = K(-0.5) * (A * dx * dx + Cc * dy * dy) - B * dx * dy;
+  return r_exp(*power);
+#endif
+}
 
 /* p' = [x y z 1] * M for a (4,4) row-major M: the reference stores its
  * matrices transposed and multiplies row vectors (graphics_utils.py:22-29). */
@@ -395,7 +429,8 @@ void gso_blend_fwd(const gso_cam* cam, const uint32_t* ranges, const uint32_t* p
           const REAL dx = means2D[2 * g] - pxf, dy = means2D[2 * g + 1] - pyf;
           const REAL A = conic_opacity[4 * g], B = conic_opacity[4 * g + 1],
                      Cc = conic_opacity[4 * g + 2], o = conic_opacity[4 * g + 3];
-          const REAL power = K(-0.5) * (A * dx * dx + Cc * dy * dy) - B * dx * dy;
+          REAL power;
+          const REAL G = gauss_value(A, B, Cc, dx, dy, &power);
           evals++;
           float perr = 0.f;
           if (margin) {
@@ -405,7 +440,7 @@ void gso_blend_fwd(const gso_cam* cam, const uint32_t* ranges, const uint32_t* p
             if (m < mg) mg = m;
           }
           if (power > K(0.0)) continue;
-          const REAL alpha = r_min(K(GSR_ALPHA_MAX), o * r_exp(power));
+          const REAL alpha = r_min(K(GSR_ALPHA_MAX), o * G);
           float rela = perr + 4e-7f;
           if (margin) {
             float m = fabsf((float)alpha - GSR_ALPHA_MIN) / ((float)alpha * rela + 1e-30f);
@@ -478,9 +513,9 @@ void gso_blend_bwd(const gso_cam* cam, const uint32_t* ranges, const uint32_t* p
           const REAL dx = means2D[2 * g] - pxf, dy = means2D[2 * g + 1] - pyf;
           const REAL A = conic_opacity[4 * g], B = conic_opacity[4 * g + 1],
                      Cc = conic_opacity[4 * g + 2], o = conic_opacity[4 * g + 3];
-          const REAL power = K(-0.5) * (A * dx * dx + Cc * dy * dy) - B * dx * dy;
+          REAL power;
+          const REAL G = gauss_value(A, B, Cc, dx, dy, &power);
           if (power > K(0.0)) continue;
-          const REAL G = r_exp(power);
           const REAL alpha = r_min(K(GSR_ALPHA_MAX), o * G);
           if (alpha < K(GSR_ALPHA_MIN)) continue;
           T = T / (K(1.0) - alpha);

@@ -28,3 +28,12 @@ def oracle64():
     import oracle
     oracle.build()
     return oracle.Oracle(np.float64)
+
+
+@pytest.fixture(scope="session")
+def oracle32k():
+    """The fp32 oracle with the Gaussian's exponent in the HIP kernels' operation order."""
+    import numpy as np
+    import oracle
+    oracle.build()
+    return oracle.Oracle(np.float32, kernel_order=True)

@@ -1,14 +1,15 @@
 """Parity at the benchmark's own sizes.
 
-C2 (100k Gaussians, 800x800, degree 3) is still small enough for the CPU oracle,
-so it is compared directly, forward and backward.  C3 (1M Gaussians, 1920x1080)
-and C5 (6M Gaussians, half of them in a hot spot at the origin, 1920x1080: the
-tile-load skew stress) are checked through properties that do not need an
-oracle: the tile lists are sorted and partition the instances, a second run is
-bit-identical in the forward, the backward is linear in the incoming gradient,
-and the two interchangeable input paths agree.  C5 is also compared with the
-oracle directly on a thinned copy of its cloud (every 30th Gaussian: the hot
-tiles keep lists of thousands of entries).
+Every workload the benchmark times is compared with the CPU oracle at FULL size, forward and backward:
+C2 (100k Gaussians, 800x800, degree 3), C3 (1M Gaussians, 1920x1080: the configuration the headline metric
+is quoted on), c3w (the C3 cloud with every opacity 0.1: no early termination, tile lists walked thousands of
+entries deep, where a forward / backward decision mismatch would show) and C5 (6M Gaussians, half of them in a
+hot spot at the origin: the tile-load skew stress).  Radii, the 22.7 M / 68.7 M tile instances with their 64-bit
+keys and the tile ranges bit-exact; the image within 1e-5 on the pixels whose threshold decisions are not within
+rounding of flipping; n_contrib exact there; gradients within 3e-5 of their largest entry.
+C3 and C5 are also checked through properties that need no oracle (sorted lists that partition the instances,
+determinism, linearity of the backward, the two interchangeable input paths), and C5 against the oracle on a
+thinned copy of its cloud.
 """
 import math
 
@@ -17,7 +18,7 @@ import pytest
 import torch
 
 from scenes import cloud_numpy, make_scene, oracle_settings
-from test_gpu_parity import MARGIN_SAFE, PIX_TOL, _gpu_settings, _rel_err
+from test_gpu_parity import MARGIN_SAFE, PIX_TOL, _gpu_settings, _rel_err, compare_input_paths
 
 pytestmark = pytest.mark.gpu
 
@@ -54,6 +55,74 @@ def test_c2_against_oracle(oracle32):
         e = _rel_err(got, g_ref[nm].reshape(got.shape))
         print("C2 grad", nm, "rel err %.2e" % e, flush=True)
         assert e < 3e-5
+
+
+FULL = {
+    # name: (P, skew_fraction, constant opacity or None) at 1920x1080, SH degree 3: the benchmark's workloads
+    "c3": (1_000_000, 0.0, None),
+    "c3w": (1_000_000, 0.0, 0.1),
+    "c5": (6_000_000, 0.5, None),
+}
+
+
+@pytest.mark.parametrize("name", list(FULL))
+def test_full_size_against_oracle(oracle32, name):
+    """gaussian_renderer/__init__.py:85-100 at the benchmark's sizes: what render() returns (image, radii) and what
+    its backward leaves in the parameters' gradients, HIP against the CPU oracle on the same cloud."""
+    import diff_gaussian_rasterization as dgr
+    P, skew, opacity = FULL[name]
+    W, H, deg = 1920, 1080, 3
+    cloud, cam, bg, _ = make_scene(P, W, H, sh_degree=deg, seed=0, skew_fraction=skew, opacity_const=opacity)
+    s_cpu, s_gpu = oracle_settings(cam, bg, deg), _gpu_settings(cam, bg, deg, 1.0)
+    cn = cloud_numpy(cloud)
+    print(name, "oracle forward ...", flush=True)
+    ref = oracle32.forward(s_cpu, **cn)
+    c = cloud.to("cuda")
+    st = dgr.rasterize_forward(s_gpu, c.xyz, c.opacity, shs=c.features, scales=c.scaling, rotations=c.rotation,
+                               keep_tile_ids=True, reference_lists=True)
+    torch.cuda.synchronize()
+    rr = ref["bin"]["ranges"].astype(np.int64).reshape(-1, 2)
+    print(name, "visible", int((ref["radii"] > 0).sum()), "instances", ref["bin"]["n_dup"], "longest tile list",
+          int((rr[:, 1] - rr[:, 0]).max()), "pixel-splat pairs evaluated by the oracle", ref["fwd"]["n_evaluated"], flush=True)
+    assert np.array_equal(st.radii.cpu().numpy(), ref["radii"])
+    assert st.num_rendered == ref["bin"]["n_dup"]
+    assert np.array_equal(st.point_list.cpu().numpy().view(np.uint32), ref["bin"]["point_list"])
+    assert np.array_equal(st.sort_keys().cpu().numpy().view(np.uint64), ref["bin"]["keys"])
+    assert np.array_equal(st.ranges.cpu().numpy().view(np.uint32), ref["bin"]["ranges"])
+    ref["bin"].pop("keys"), ref["bin"].pop("keys_unsorted"), ref["bin"].pop("vals_unsorted")   # gigabytes at 6M
+    st.tile_ids_sorted = None
+    vis = ref["radii"] > 0
+    for nm, got, want in (("means2D", st.means2D, ref["pre"]["means2D"]), ("conic_opacity", st.conic_opacity, ref["pre"]["conic_opacity"]),
+                          ("rgb", st.rgb, ref["pre"]["rgb"]), ("depths", st.depths, ref["pre"]["depths"])):
+        g = np.ascontiguousarray(got.cpu().numpy(), dtype=np.float32).view(np.uint32)
+        w = np.ascontiguousarray(want, dtype=np.float32).view(np.uint32)
+        assert np.array_equal(g[vis], w[vis]), nm
+    safe = ref["fwd"]["margin"] >= MARGIN_SAFE
+    print(name, "threshold-borderline pixels: %.4f%%" % (100 * (1.0 - safe.mean())), flush=True)
+    # a pixel of the low-opacity cloud takes some 1500 keep / skip decisions before it saturates, ten times as many
+    # as in the other workloads, so more pixels have one within rounding of its threshold (1.5 % against 0.2 %)
+    assert 1.0 - safe.mean() < (3e-2 if name == "c3w" else 5e-3)
+    diff = np.abs(st.color.cpu().numpy() - ref["color"])
+    print(name, "max |image - oracle| on safe pixels %.2e, anywhere %.2e" % (diff[:, safe].max(), diff.max()), flush=True)
+    assert diff[:, safe].max() <= PIX_TOL
+    assert diff.max() < 2e-2
+    assert np.array_equal(st.n_contrib.cpu().numpy().view(np.uint32)[safe], ref["fwd"]["n_contrib"][safe])
+    np.testing.assert_allclose(st.final_T.cpu().numpy()[safe], ref["fwd"]["final_T"][safe], rtol=2e-5, atol=1e-7)
+
+    dL = np.random.default_rng(1).standard_normal((3, H, W)).astype(np.float32) * safe[None]
+    print(name, "oracle backward ...", flush=True)
+    g_ref = oracle32.backward(s_cpu, ref, dL, cn["means3D"], scales=cn["scales"], rotations=cn["rotations"],
+                              shs=cn["shs"])
+    g = dgr.rasterize_backward(s_gpu, st, torch.from_numpy(dL).cuda(), c.xyz, shs=c.features, scales=c.scaling,
+                               rotations=c.rotation)
+    for nm in ("means3D", "means2D", "shs", "opacities", "scales", "rotations"):
+        got = g[nm].cpu().numpy()
+        e = _rel_err(got, g_ref[nm].reshape(got.shape))
+        print(name, "grad", nm, "rel err %.2e" % e, flush=True)
+        assert e < 3e-5, (nm, e)
+        assert np.isfinite(got).all()
+    del st, c, g, ref, g_ref
+    torch.cuda.empty_cache()
 
 
 BIG = {
@@ -200,19 +269,24 @@ def test_c3_backward_is_linear_in_the_incoming_gradient(c3):
 
 def test_c3_interchangeable_input_paths(c3):
     """colors_precomp = clamp(eval_sh + 0.5) and cov3D_precomp = covariance(scales, rotations)
-    (gaussian_renderer/__init__.py:62-66, 72-80) render the same image."""
+    (gaussian_renderer/__init__.py:62-66, 72-80) render the same image and give the same gradient of every
+    parameter, at full size, through the nn.Module and autograd."""
     dgr, s, c, st = c3
-    from gsplat_host.model import covariance_from_scaling_rotation
-    from gsplat_host.sh import eval_sh
-    d = c.xyz - s.campos[None]
-    d = d / d.norm(dim=1, keepdim=True)
-    col = torch.clamp_min(eval_sh(3, c.features.transpose(1, 2), d) + 0.5, 0.0)
-    cov = covariance_from_scaling_rotation(c.scaling, 1.0, c.rotation)
-    st2 = dgr.rasterize_forward(s, c.xyz, c.opacity, colors_precomp=col, cov3D_precomp=cov, reference_lists=True)
-    torch.cuda.synchronize()
-    assert float((st2.radii != st.radii).float().mean()) < 1e-4
-    diff = (st2.color - st.color).abs()
-    assert float(diff.mean()) < 1e-5 and float((diff > 1e-3).float().mean()) < 1e-3
+    rast = dgr.GaussianRasterizer(raster_settings=s)
+    leaf = lambda t: t.detach().clone().requires_grad_(True)
+    m3, op, sc, ro, sh = leaf(c.xyz), leaf(c.opacity), leaf(c.scaling), leaf(c.rotation), leaf(c.features)
+    sink = torch.zeros_like(m3, requires_grad=True)
+    img, radii = rast(means3D=m3, means2D=sink, shs=sh, colors_precomp=None, opacities=op, scales=sc, rotations=ro,
+                      cov3D_precomp=None)
+    assert torch.equal(img, st.color) and torch.equal(radii, st.radii)
+    w = torch.randn(img.shape, device="cuda", generator=torch.Generator(device="cuda").manual_seed(5))
+    (img * w).sum().backward()
+    errs = compare_input_paths(rast, s, c, w, img.detach(), radii, dict(
+        means3D=m3.grad, opacities=op.grad, shs=sh.grad, scales=sc.grad, rotations=ro.grad, means2D=sink.grad))
+    print("two input paths at full size, gradients (largest error, share beyond 1e-4):",
+          {k: "%.1e %.1e" % v for k, v in errs.items()}, flush=True)
+    del m3, op, sc, ro, sh, sink, img
+    torch.cuda.empty_cache()
 
 
 def test_c5_thinned_cloud_against_oracle(oracle32):

@@ -54,13 +54,16 @@ CASES = {
 }
 
 
-# faint, overlapping needles leave more pixels within rounding distance of a 1/255 decision, and
-# their conics are ill-conditioned: the exponent is a small difference of large terms, so the two
-# roundings of it (C float expression order there, fused multiply-adds in the log2 domain here)
-# differ by up to ~1e-4 relative in alpha
+# Faint, overlapping needles leave more pixels within rounding distance of a 1/255 decision, and
+# their conics are ill-conditioned: the exponent is a small difference of large terms, so two
+# roundings of it (the published expression's order in the default oracle, fused multiply-adds in the
+# log2 domain in the kernels) differ by up to ~1e-4 relative in alpha.  No tolerance is widened for that:
+# the scene is compared at the ordinary bars with the oracle build that evaluates the exponent in the
+# kernels' order (oracle32k), and against the default oracle the allowance is the measured distance
+# between the two oracle builds themselves (triangle inequality), printed beside the observed error.
 MAX_BORDERLINE = {"needles": 1e-2}
-LOOSE = {"needles": 30.0}      # factor on the blend tolerances
-LOOSE_GEOMETRY = {"needles": 300.0}   # ... and on gradients that pass through the inverse of a near-singular 2x2
+ILL_CONDITIONED = ("needles",)
+GRADS = ("means3D", "means2D", "shs", "opacities", "scales", "rotations")
 
 
 def _run_case(oracle32, name, reference_lists=True):
@@ -78,8 +81,26 @@ def _run_case(oracle32, name, reference_lists=True):
     return cloud, cam, bg, mod, s_cpu, s_gpu, cn, ref, st
 
 
+def _check_ill_conditioned_forward(oracle32k, name, s_cpu, cn, ref, st):
+    """Image and final_T at the ordinary bars against the kernel-order oracle; against the default oracle
+    within those bars plus the distance between the two oracle builds."""
+    refk = oracle32k.forward(s_cpu, **cn)
+    fw, fk = ref["fwd"], refk["fwd"]
+    color, final_T = st.color.cpu().numpy(), st.final_T.cpu().numpy()
+    safe = (fw["margin"] >= MARGIN_SAFE) & (fk["margin"] >= MARGIN_SAFE)
+    assert np.array_equal(st.n_contrib.cpu().numpy().view(np.uint32)[safe], fk["n_contrib"][safe])
+    err_k = np.abs(color - fk["color"])[:, safe].max()
+    between = np.abs(fk["color"] - fw["color"])[:, safe].max()
+    err_c = np.abs(color - fw["color"])[:, safe].max()
+    print(name, "image: vs kernel-order oracle %.2e, vs default oracle %.2e, the two oracles apart %.2e"
+          % (err_k, err_c, between), flush=True)
+    assert err_k <= PIX_TOL, err_k
+    assert err_c <= PIX_TOL + between, (err_c, between)
+    np.testing.assert_allclose(final_T[safe], fk["final_T"][safe], rtol=2e-5, atol=1e-7)
+
+
 @pytest.mark.parametrize("name", list(CASES))
-def test_forward_stages(oracle32, name):
+def test_forward_stages(oracle32, oracle32k, name):
     cloud, cam, bg, mod, s_cpu, s_gpu, cn, ref, st = _run_case(oracle32, name)
     pre, bn, fw = ref["pre"], ref["bin"], ref["fwd"]
     print(name, "P", st.P, "visible", int((pre["radii"] > 0).sum()), "instances", bn["n_dup"], flush=True)
@@ -110,15 +131,18 @@ def test_forward_stages(oracle32, name):
     print(name, "threshold-borderline pixels: %.4f%%" % (100 * frac_unsafe), flush=True)
     assert frac_unsafe < MAX_BORDERLINE.get(name, 5e-3)
     diff = np.abs(color - fw["color"])
-    loose = LOOSE.get(name, 1.0)
-    assert diff[:, safe].max() <= PIX_TOL * loose, diff[:, safe].max()
+    if name in ILL_CONDITIONED:
+        _check_ill_conditioned_forward(oracle32k, name, s_cpu, cn, ref, st)
+    else:
+        print(name, "max |image - oracle| on safe pixels: %.2e" % diff[:, safe].max(), flush=True)
+        assert diff[:, safe].max() <= PIX_TOL, diff[:, safe].max()
+        np.testing.assert_allclose(st.final_T.cpu().numpy()[safe], fw["final_T"][safe], rtol=2e-5, atol=1e-7)
     assert diff.max() < 2e-2                       # a flipped decision moves a pixel by one contribution at most
     assert np.array_equal(st.n_contrib.cpu().numpy().view(np.uint32)[safe], fw["n_contrib"][safe])
-    np.testing.assert_allclose(st.final_T.cpu().numpy()[safe], fw["final_T"][safe], rtol=2e-5 * loose, atol=1e-7)
 
 
 @pytest.mark.parametrize("name", list(CASES))
-def test_forward_with_short_lists(oracle32, name):
+def test_forward_with_short_lists(oracle32, oracle32k, name):
     """The optional short lists leave out the tiles that the bounding box of a Gaussian's
     alpha >= 1/255 ellipse cannot reach: every list is the module's list with entries removed (same
     order), and the image is the one the module's lists give, bit for bit."""
@@ -150,7 +174,11 @@ def test_forward_with_short_lists(oracle32, name):
     fw = ref["fwd"]
     safe = fw["margin"] >= MARGIN_SAFE
     diff = np.abs(st.color.cpu().numpy() - fw["color"])
-    assert diff[:, safe].max() <= PIX_TOL * LOOSE.get(name, 1.0)
+    if name in ILL_CONDITIONED:
+        fk = oracle32k.forward(s_cpu, **cn)["fwd"]
+        safe = fk["margin"] >= MARGIN_SAFE
+        diff = np.abs(st.color.cpu().numpy() - fk["color"])
+    assert diff[:, safe].max() <= PIX_TOL
 
 
 def _rel_err(got, ref):
@@ -158,9 +186,25 @@ def _rel_err(got, ref):
     return np.abs(got - ref).max() / scale
 
 
-@pytest.mark.parametrize("name", ["c1_10k_256_deg0", "ragged_5k_333x200_deg3", "deg1_close_camera",
-                                  "skewed_hot_tiles", "low_opacity_no_termination", "needles"])
-def test_backward(oracle32, name):
+BACKWARD_CASES = ["c1_10k_256_deg0", "ragged_5k_333x200_deg3", "deg1_close_camera", "skewed_hot_tiles",
+                  "low_opacity_no_termination", "needles"]
+
+
+def _backward_errors(orc, s_cpu, cn, ref, dL, g, ds):
+    """Relative errors (of the largest entry) of the GPU's gradients against one oracle build's."""
+    g_ref = orc.backward(s_cpu, ref, dL, cn["means3D"], scales=cn["scales"], rotations=cn["rotations"], shs=cn["shs"])
+    bb = g_ref["blend"]
+    blend = {nm: _rel_err(ds[nm], bb[key]) for nm, key in (("mean2D", "dL_dmean2D"), ("conic", "dL_dconic"),
+                                                           ("opacity", "dL_dopacity"), ("color", "dL_dcolor"))}
+    full = {nm: _rel_err(g[nm], g_ref[nm].reshape(g[nm].shape)) for nm in GRADS}
+    return blend, full, g_ref
+
+
+@pytest.mark.parametrize("name", BACKWARD_CASES)
+def test_backward(oracle32, oracle32k, name):
+    """Gradients at 2e-5 (blend sums) / 3e-5 (op inputs) of the largest entry.  Every scene against the default
+    oracle; the ill-conditioned one against the kernel-order oracle at the same bars, and against the default
+    oracle within those bars plus the measured distance between the two oracle builds."""
     import diff_gaussian_rasterization as dgr
     cloud, cam, bg, mod, s_cpu, s_gpu, cn, ref, st = _run_case(oracle32, name)
     rng = np.random.default_rng(3)
@@ -169,35 +213,116 @@ def test_backward(oracle32, name):
     # legitimately differ in fp32 (oracle margin below MARGIN_SAFE, ~0.1-0.2 % of pixels) get a zero
     # loss gradient, so that what is compared is the backward arithmetic on identical decisions.
     safe = ref["fwd"]["margin"] >= MARGIN_SAFE
+    refk = None
+    if name in ILL_CONDITIONED:
+        refk = oracle32k.forward(s_cpu, **cn)
+        safe &= refk["fwd"]["margin"] >= MARGIN_SAFE
     dL *= safe[None].astype(np.float32)
-    g_ref = oracle32.backward(s_cpu, ref, dL, cn["means3D"], scales=cn["scales"], rotations=cn["rotations"],
-                              shs=cn["shs"])
     c = cloud.to("cuda")
     dLg = torch.from_numpy(dL).cuda()
     dsplat = dgr.blend_backward(st, dLg)
     g = dgr.rasterize_backward(s_gpu, st, dLg, c.xyz, shs=c.features, scales=c.scaling, rotations=c.rotation,
                                dsplat=dsplat)
     torch.cuda.synchronize()
+    g = {k: v.cpu().numpy() for k, v in g.items() if v is not None}
+    assert all(np.isfinite(v).all() for v in g.values())
     ds = {k: v.cpu().numpy() for k, v in dgr.splat_sums_to_grads(st, dsplat).items()}
-    bb = g_ref["blend"]
-    for nm, got, want in [("mean2D", ds["mean2D"], bb["dL_dmean2D"]), ("conic", ds["conic"], bb["dL_dconic"]),
-                          ("opacity", ds["opacity"], bb["dL_dopacity"]), ("color", ds["color"], bb["dL_dcolor"])]:
-        e = _rel_err(got, want)
-        print(name, "blend_bwd", nm, "rel err %.2e" % e, flush=True)
-        assert e < 2e-5 * LOOSE.get(name, 1.0), (nm, e)
-    for nm in ("means3D", "means2D", "shs", "opacities", "scales", "rotations"):
-        got, want = g[nm].cpu().numpy(), g_ref[nm]
-        e = _rel_err(got, want.reshape(got.shape))
-        print(name, "grad", nm, "rel err %.2e" % e, flush=True)
-        assert e < 3e-5 * (LOOSE_GEOMETRY if nm in ("scales", "rotations") else LOOSE).get(name, 1.0), (nm, e)
-        assert np.isfinite(got).all()
+    blend, full, g_ref = _backward_errors(oracle32, s_cpu, cn, ref, dL, g, ds)
+    if refk is None:
+        for nm, e in blend.items():
+            print(name, "blend_bwd", nm, "rel err %.2e" % e, flush=True)
+            assert e < 2e-5, (nm, e)
+        for nm, e in full.items():
+            print(name, "grad", nm, "rel err %.2e" % e, flush=True)
+            assert e < 3e-5, (nm, e)
+        return
+    blend_k, full_k, g_refk = _backward_errors(oracle32k, s_cpu, cn, refk, dL, g, ds)
+    for nm in blend:
+        print(name, "blend_bwd", nm, "rel err vs kernel-order oracle %.2e, vs default oracle %.2e" % (blend_k[nm], blend[nm]),
+              flush=True)
+        assert blend_k[nm] < 2e-5, (nm, blend_k[nm])
+    for nm in GRADS:
+        between = _rel_err(g_refk[nm], g_ref[nm])
+        print(name, "grad", nm, "rel err vs kernel-order oracle %.2e, vs default oracle %.2e, the two oracles apart %.2e"
+              % (full_k[nm], full[nm], between), flush=True)
+        assert full_k[nm] < 3e-5, (nm, full_k[nm])
+        assert full[nm] < 3e-5 + 1.01 * between, (nm, full[nm], between)
+
+
+@pytest.mark.parametrize("name", ["ragged_5k_333x200_deg3", "skewed_hot_tiles", "low_opacity_no_termination"])
+def test_backward_against_the_kernel_order_oracle(oracle32k, name):
+    """The well-conditioned scenes pass against either oracle build (the builds differ by rounding only)."""
+    import diff_gaussian_rasterization as dgr
+    cloud, cam, bg, mod, s_cpu, s_gpu, cn, ref, st = _run_case(oracle32k, name)
+    safe = ref["fwd"]["margin"] >= MARGIN_SAFE
+    diff = np.abs(st.color.cpu().numpy() - ref["color"])
+    assert diff[:, safe].max() <= PIX_TOL
+    assert np.array_equal(st.n_contrib.cpu().numpy().view(np.uint32)[safe], ref["fwd"]["n_contrib"][safe])
+    dL = np.random.default_rng(4).standard_normal((3, cam.image_height, cam.image_width)).astype(np.float32) * safe[None]
+    c = cloud.to("cuda")
+    dLg = torch.from_numpy(dL).cuda()
+    dsplat = dgr.blend_backward(st, dLg)
+    g = dgr.rasterize_backward(s_gpu, st, dLg, c.xyz, shs=c.features, scales=c.scaling, rotations=c.rotation, dsplat=dsplat)
+    g = {k: v.cpu().numpy() for k, v in g.items() if v is not None}
+    ds = {k: v.cpu().numpy() for k, v in dgr.splat_sums_to_grads(st, dsplat).items()}
+    blend, full, _ = _backward_errors(oracle32k, s_cpu, cn, ref, dL, g, ds)
+    assert all(e < 2e-5 for e in blend.values()), blend
+    assert all(e < 3e-5 for e in full.values()), full
+
+
+def compare_input_paths(rast, s, c, w, img, radii, grads, degree=3, tol=1e-4):
+    """The reference's two interchangeable input paths (gaussian_renderer/__init__.py:62-66 and :72-80):
+    ``colors_precomp = clamp_min(eval_sh(shs) + 0.5, 0)`` and ``cov3D_precomp = covariance(scales, rotations)``
+    evaluated in PyTorch WITH autograd and handed to the operator, against the operator fed ``shs``, ``scales``
+    and ``rotations`` directly (``img``, ``radii``, ``grads`` of loss = sum(img * w)).  Same image, and the same
+    gradient of every parameter (the second path's reach SH coefficients, scales and rotations through PyTorch's
+    backward of eval_sh and of the covariance): within ``tol`` of the largest entry, over the Gaussians whose
+    radius is the same on both paths (a covariance rounded differently flips a ceil() for a few in ten thousand).
+    A flipped radius changes which tiles that Gaussian is listed in, i.e. it adds or removes a faint contribution
+    (alpha <= 0.011) on a few pixels, and with it the transmittance of everything behind it there; the handful of
+    Gaussians that sit behind one may therefore differ by more: at most one in ten thousand may exceed ``tol``, none
+    ten times ``tol``.  Returns {name: (largest relative error, share of Gaussians beyond tol)}."""
+    from gsplat_host.model import covariance_from_scaling_rotation
+    from gsplat_host.sh import eval_sh
+    leaf = lambda t: t.detach().clone().requires_grad_(True)
+    m3, op, sc, ro, sh = leaf(c.xyz), leaf(c.opacity), leaf(c.scaling), leaf(c.rotation), leaf(c.features)
+    d = m3 - s.campos[None]
+    d = d / d.norm(dim=1, keepdim=True)
+    col = torch.clamp_min(eval_sh(degree, sh.transpose(1, 2), d) + 0.5, 0.0)
+    cov = covariance_from_scaling_rotation(sc, 1.0, ro)
+    col.retain_grad()
+    cov.retain_grad()
+    sink = torch.zeros_like(m3, requires_grad=True)
+    img2, radii2 = rast(means3D=m3, means2D=sink, shs=None, colors_precomp=col, opacities=op, scales=None,
+                        rotations=None, cov3D_precomp=cov)
+    (img2 * w).sum().backward()
+    assert col.grad.shape == (c.xyz.shape[0], 3) and cov.grad.shape == (c.xyz.shape[0], 6)
+    same = radii2 == radii
+    assert float((~same).float().mean()) < 1e-3
+    diff = (img2 - img).abs()
+    assert float(diff.max()) < 2e-2 and float(diff.mean()) < 1e-5 and float((diff > 1e-4).float().mean()) < 1e-3
+    got = dict(means3D=m3.grad, opacities=op.grad, shs=sh.grad, scales=sc.grad, rotations=ro.grad, means2D=sink.grad)
+    # The covariance helper normalises the quaternion (utils/general_utils.py:79-81), the operator takes it as
+    # given: the first path's rotation gradient has a component along q that the second projects out, exactly
+    # as normalize() does for the model's raw rotations in the reference (scene/gaussian_model.py:100-101).
+    q = c.rotation / c.rotation.norm(dim=1, keepdim=True)
+    tangent = lambda g: g - q * (q * g).sum(dim=1, keepdim=True)
+    errs = {}
+    for k, want in grads.items():
+        have = got[k]
+        if k == "rotations":
+            have, want = tangent(have), tangent(want)
+        scale = float(want.abs().max()) + 1e-20
+        per = (have[same] - want[same]).abs().reshape(int(same.sum()), -1).amax(dim=1) / scale
+        errs[k] = (float(per.max()), float((per > tol).float().mean()))
+    assert all(worst <= 10 * tol and beyond <= 1e-4 for worst, beyond in errs.values()), errs
+    return errs
 
 
 def test_module_api_and_alternative_inputs(oracle32):
     """The nn.Module surface, autograd wiring, and the two interchangeable input
     paths of the reference (gaussian_renderer/__init__.py:62-66 and :72-80)."""
     import diff_gaussian_rasterization as dgr
-    from oracle import torch_ref
     cloud, cam, bg, _ = make_scene(4_000, 200, 120, sh_degree=3, seed=5, bg=(0.3, 0.3, 0.3))
     s = _gpu_settings(cam, bg, 3, 1.0)
     c = cloud.to("cuda")
@@ -220,20 +345,11 @@ def test_module_api_and_alternative_inputs(oracle32):
         oracle32.mark_visible(oracle_settings(cam, bg, 3, 1.0), cloud.xyz.numpy())))
 
     # SH evaluated in Python and handed over as colors_precomp; covariance precomputed in Python
-    with torch.no_grad():
-        d = c.xyz - s.campos[None]
-        d = d / d.norm(dim=1, keepdim=True)
-        col = torch.clamp_min(torch_ref.sh_to_rgb(3, c.features, d) + 0.5, 0.0)
-        cov = torch_ref.cov3d(c.scaling, 1.0, c.rotation)
-    col, cov = leaf(col), leaf(cov)
-    m3b, opb = leaf(c.xyz), leaf(c.opacity)
-    img2, radii2 = rast(means3D=m3b, means2D=torch.zeros_like(m3b, requires_grad=True), shs=None, colors_precomp=col,
-                        opacities=opb, scales=None, rotations=None, cov3D_precomp=cov)
-    (img2 * w).sum().backward()
-    assert float((img2 - img).abs().max()) < 2e-2 and float((img2 - img).abs().mean()) < 1e-5
-    assert (radii2 != radii).float().mean() < 1e-3
-    assert _rel_err(opb.grad.cpu().numpy(), op.grad.cpu().numpy()) < 1e-2
-    assert col.grad.shape == (4000, 3) and cov.grad.shape == (4000, 6)
+    errs = compare_input_paths(rast, s, c, w, img, radii, dict(means3D=m3.grad, opacities=op.grad, shs=sh.grad,
+                                                                scales=sc.grad, rotations=ro.grad, means2D=sink.grad))
+    print("two input paths, gradients (largest error, share beyond 1e-4):", {k: "%.1e %.1e" % v for k, v in errs.items()}, flush=True)
+    col = torch.rand((4000, 3), device="cuda")
+    cov = c.scaling.new_zeros((4000, 6))
 
     with pytest.raises(Exception):
         rast(means3D=m3, means2D=sink, shs=sh, colors_precomp=col, opacities=op, scales=sc, rotations=ro)
