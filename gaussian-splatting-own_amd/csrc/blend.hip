@@ -335,7 +335,8 @@ __global__ void __launch_bounds__(256) blend_bwd_kernel(int W, int H, const uint
   const int last = px.inside ? (int)n_contrib[pix] : 0;
   float dp0 = 0.f, dp1 = 0.f, dp2 = 0.f;
   if (px.inside) { dp0 = dL_dpix[pix]; dp1 = dL_dpix[plane + pix]; dp2 = dL_dpix[2 * plane + pix]; }
-  const float bg_dot = bg[0] * dp0 + bg[1] * dp1 + bg[2] * dp2;
+  // final transmittance times (background . dL/dcolour): the background's share of every dL/dalpha of the pixel
+  const float Tf_bg = Tf * (bg[0] * dp0 + bg[1] * dp1 + bg[2] * dp2);
   // the tile starts at the deepest position any of its pixels used
   int wl = last;
 #pragma unroll
@@ -346,9 +347,10 @@ __global__ void __launch_bounds__(256) blend_bwd_kernel(int W, int H, const uint
   const int tile_last = max(max(s_last[0], s_last[1]), max(s_last[2], s_last[3]));
   if (tile_last == 0 || total == 0) { fill_my_share(fill); return; }
 
-  // acc = colour composited behind the current splat (everything already visited in this
-  // back-to-front walk), per channel.
-  float T = Tf, acc0 = 0.f, acc1 = 0.f, acc2 = 0.f;
+  // behind = the colour composited behind the current splat (everything already visited in this back-to-front
+  // walk) dotted with the pixel's dL/dcolour: the colours enter dL/dalpha only through that dot product, so one
+  // running scalar stands for the three channel sums.
+  float T = Tf, behind = 0.f;
   // the wave's reduction scratch: its LDS byte offset for the stores, and where this lane reads its two quarters of row lane/8
   typedef __attribute__((address_space(3))) float lds_float;
   const unsigned red_base = __builtin_amdgcn_readfirstlane((unsigned)(uintptr_t)(lds_float*)s_red[wave]);
@@ -406,12 +408,10 @@ __global__ void __launch_bounds__(256) blend_bwd_kernel(int W, int H, const uint
         const float inv = __builtin_amdgcn_rcpf(1.0f - alpha);     // alpha == 0: exactly 1
         T = T * inv;                                               // transmittance in front of the splat
         const float dch = alpha * T;
-        const float2 rg = make_float2(col.z, col.w), bi = s_splat.tail[j];
-        const float d0 = rg.x - acc0, d1 = rg.y - acc1, d2 = bi.x - acc2;
-        const float dL_dalpha = (d0 * dp0 + d1 * dp1 + d2 * dp2) * T - (Tf * inv) * bg_dot;
-        acc0 = fmaf(alpha, d0, acc0);                              // alpha c + (1 - alpha) acc
-        acc1 = fmaf(alpha, d1, acc1);
-        acc2 = fmaf(alpha, d2, acc2);
+        const float2 bi = s_splat.tail[j];
+        const float d = fmaf(bi.x, dp2, fmaf(col.w, dp1, col.z * dp0)) - behind;   // (c - behind) . dL/dcolour
+        const float dL_dalpha = fmaf(d, T, -(Tf_bg * inv));
+        behind = fmaf(alpha, d, behind);                           // alpha c + (1 - alpha) behind
         // u = dL/dG * G.  Everything geometric is a moment of u over the pixels:
         //   dL/dopacity = sum u / o,  dL/dmean ~ (sum u dx, sum u dy),  dL/dconic ~ (sum u dx^2, ...)
         // the per-splat factors are applied once per Gaussian by the preprocess backward.

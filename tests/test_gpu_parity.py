@@ -237,16 +237,32 @@ def test_backward(oracle32, oracle32k, name):
             assert e < 3e-5, (nm, e)
         return
     blend_k, full_k, g_refk = _backward_errors(oracle32k, s_cpu, cn, refk, dL, g, ds)
+    # (1) what the blend backward leaves per Gaussian, at the ordinary bar against the kernel-order oracle
     for nm in blend:
         print(name, "blend_bwd", nm, "rel err vs kernel-order oracle %.2e, vs default oracle %.2e" % (blend_k[nm], blend[nm]),
               flush=True)
         assert blend_k[nm] < 2e-5, (nm, blend_k[nm])
+    # (2) the per-Gaussian backward is the oracle's function: fed the GPU's own per-Gaussian sums, the oracle's
+    # preprocess backward returns the GPU's gradients.  (The map from the conic's gradient to the covariance's goes
+    # through the inverse of a near-singular 2x2 here, so it amplifies the 1e-6 summation-order differences of (1)
+    # several hundred times: end to end, means3D / scales / rotations are NOT within 3e-5 on this scene against
+    # any oracle that sums in another order, and that number is printed, not asserted.)
+    bb = dict(dL_dmean2D=ds["mean2D"], dL_dconic=ds["conic"], dL_dopacity=ds["opacity"], dL_dcolor=ds["color"])
+    pb = oracle32k.preprocess_bwd(s_cpu, refk["pre"], bb, cn["means3D"], cn["scales"], cn["rotations"], cn["shs"])
+    same_inputs = dict(means3D=pb["dL_dmeans3D"], shs=pb["dL_dshs"], scales=pb["dL_dscales"], rotations=pb["dL_drotations"])
+    for nm, want in same_inputs.items():
+        e = _rel_err(g[nm], want.reshape(g[nm].shape))
+        print(name, "grad", nm, "rel err vs the oracle's per-Gaussian backward on the same sums %.2e" % e, flush=True)
+        assert e < 3e-5, (nm, e)
     for nm in GRADS:
         between = _rel_err(g_refk[nm], g_ref[nm])
-        print(name, "grad", nm, "rel err vs kernel-order oracle %.2e, vs default oracle %.2e, the two oracles apart %.2e"
+        print(name, "grad", nm, "end to end: rel err vs kernel-order oracle %.2e, vs default oracle %.2e, the two oracles apart %.2e"
               % (full_k[nm], full[nm], between), flush=True)
-        assert full_k[nm] < 3e-5, (nm, full_k[nm])
-        assert full[nm] < 3e-5 + 1.01 * between, (nm, full[nm], between)
+        if nm in ("means2D", "opacities", "shs"):             # linear in the sums of (1) with bounded coefficients
+            assert full_k[nm] < 3e-5, (nm, full_k[nm])
+        # a loose ceiling on the amplified figure (it moves with the order in which the float atomics land: 1.8e-3
+        # and 2.9e-3 for the scales in two runs of the same code); steps (1) and (2) are the parity statement here
+        assert full_k[nm] < 1e-2 and full[nm] < 1e-2 + between, (nm, full_k[nm], full[nm])
 
 
 @pytest.mark.parametrize("name", ["ragged_5k_333x200_deg3", "skewed_hot_tiles", "low_opacity_no_termination"])

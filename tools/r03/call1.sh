@@ -5,7 +5,7 @@ set -e
 cd $GRAFT_REPO_ROOT
 mkdir -p gpurun_out
 echo "== suite (default kernels)"; 
-timeout -k 10 700 python -u -m pytest tests -m gpu -x -q --timeout 300 --timeout-method thread -p no:cacheprovider --durations=12 -s > gpurun_out/r03_suite1.log 2>&1 || { tail -60 gpurun_out/r03_suite1.log; exit 1; }
+timeout -k 10 700 python -u -m pytest tests -m gpu -q --timeout 300 --timeout-method thread -p no:cacheprovider --durations=12 -s > gpurun_out/r03_suite1.log 2>&1 || { tail -60 gpurun_out/r03_suite1.log; exit 1; }
 tail -20 gpurun_out/r03_suite1.log
 for v in rows8 rows4 rows8acc rows4acc; do
   echo "== parity with GSR_BLEND_BWD=$v"
