@@ -24,13 +24,20 @@ over ranks, measured with device events inside the timed training steps;
 `ms_per_step` is the whole train step.  `roofline` prices the dominant
 hand-written kernel against HBM with the ALGORITHMIC bytes of one launch over
 the kernel's own duration (events stamped by the launch itself, not brackets on
-the stream), and says from committed counter runs which of HBM, vector issue and
-LDS is closest to its limit; `cpu_baseline` times the C oracle's forward render
-of the same workload on the host cores (rank 0, N=1 only).  On the default
-workload at one GPU the line also carries, as `variants`, the same step through
-the reference's unchanged operator API (PyTorch activations feeding
-GaussianRasterizer) and on the no-early-termination scene (every opacity 0.1,
-the reference's initial value, scene/gaussian_model.py:139).
+the stream): that is `achieved` / `frac`, an upper bound on what the kernel moves.
+Beside it the line says, from committed counter runs of the same workload, what
+the kernel measurably does: `frac_measured_bytes` (HBM bytes counted by the
+hardware over the same time), the busiest unit and its fraction, and `bound` =
+that unit when it is above 80 % of its peak, "latency" otherwise.  `lists`
+gives the measured tile-list statistics (instances, longest and mean list, how
+deep the lists are walked, pixel-splat pairs).  `cpu_baseline` times the C
+oracle's forward render of the same workload on the host cores (rank 0, N=1
+only).  On the default workload at one GPU the line also carries the same step
+through the reference's unchanged operator API (`reference_operator_api`:
+PyTorch activations feeding GaussianRasterizer, what a user of the drop-in gets
+without changing a line), and as `variants` the no-early-termination scene
+(every opacity 0.1, the reference's initial value, scene/gaussian_model.py:139)
+and the skewed 6M cloud with the same opacities (c5w).
 """
 from __future__ import annotations
 
@@ -61,6 +68,8 @@ WORKLOADS = {
     # the C3 cloud with every opacity 0.1: no pixel saturates early, every tile list is walked far deeper
     "c3w": (1_000_000, 1920, 1080, 3, 0.0, 0.1),
     "c5": (6_000_000, 1920, 1080, 3, 0.5, None),
+    # the worst case for tile-load skew: the C5 cloud (half of the Gaussians in a hot spot) with every opacity 0.1
+    "c5w": (6_000_000, 1920, 1080, 3, 0.5, 0.1),
 }
 
 SETTLE_STEPS = 40                 # untimed steps a measurement starts with, the W warm-up steps included
@@ -137,6 +146,8 @@ def limits(kernel, ms, alg_bytes, counters, source):
     real = {k: v for k, v in fr.items() if k != "hbm_algorithmic"}
     if real:
         top = max(real, key=real.get)
+        out["busiest_unit"], out["busiest_unit_frac"] = top, round(real[top], 3)
+        out["bound"] = top if real[top] > 0.8 else "latency"
         out["limited_by"] = {"hbm_measured": "HBM bandwidth", "valu_issue": "vector-instruction issue",
                              "lds_array": "the LDS"}[top] + f" is the busiest unit ({real[top]:.0%} of its peak; " + \
             ", ".join(f"{k} {v:.0%}" for k, v in real.items() if k != top) + ")" + \
@@ -287,6 +298,8 @@ def main():
         print(f"warning: --gpus {args.gpus} but WORLD_SIZE {world}", file=sys.stderr)
 
     import diff_gaussian_rasterization as dgr
+    # one process per GPU and nothing else on it: the depth sort may give workgroup b chunk b instead of a ticket
+    dgr.assume_exclusive_device(True)
     if args.short_lists:
         dgr.REFERENCE_LISTS = False
     from gsplat_host.optim import GaussianAdam
@@ -323,7 +336,8 @@ def main():
         for k, (mean, lo, hi, n) in m["exact"].items():
             stage_ms[k] = mean                     # the blend kernels: the kernel's own duration inside the timed steps
         N = m["visible"]
-        st_N = _instances(dgr, scene)
+        lists = _list_stats(dgr, scene)
+        st_N = lists["instances"]
         alg = algorithmic_bytes(P, st_N, W, H)
         # The roofline object is about the blend backward, the longest kernel of the headline workload.  On a
         # workload where another stage outlasts it (6M Gaussians: the per-Gaussian backward) that is said on
@@ -357,11 +371,17 @@ def main():
                                    "(activations + render + 0.8*L1+0.2*(1-SSIM) + backward), one view per GPU",
                        "gaussians": P, "visible": N, "tile_instances": st_N, "views_per_step": world,
                        "activations": "torch ops (as the reference)" if args.unfused else "in the preprocess kernels",
-                       "tile_lists": "short (ellipse bounding boxes)" if args.short_lists else "the reference's"},
+                       "tile_lists": "short (ellipse bounding boxes)" if args.short_lists else "the reference's",
+                       "exclusive_device": True},
+            "lists": lists,
             "train_step_ms": round(ms_per_step, 3), "render_ms": round(render_ms, 3),
             "render_Ginstances_per_s": round(world * st_N / (render_ms * 1e-3) / 1e9, 2),
-            "roofline": {"bound": "hbm", "kernel": dominant, "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS,
+            "roofline": {"bound": lim.pop("bound", "unmeasured (no committed counters for this workload)"),
+                         "priced_against": "hbm: achieved = algorithmic bytes of one launch / kernel time; an upper bound on "
+                                           "what the kernel moves, not a utilisation (see frac_measured_bytes)",
+                         "kernel": dominant, "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS,
                          "unit": "GB/s", "frac": round(achieved / HBM_PEAK_GBS, 4),
+                         "frac_measured_bytes": lim.get("fractions_of_peak", {}).get("hbm_measured"),
                          "traffic": lim.get("measured_hbm_bytes"),
                          "traffic_unit": "bytes/launch (rocprofv3 FETCH_SIZE x2 + WRITE_SIZE)",
                          "kernel_ms": round(dom_ms, 4),
@@ -383,7 +403,7 @@ def main():
                                  else "none (the mean loss, one scalar, once per timed region)",
         }
         if world == 1 and args.workload == "c3" and not args.no_variants and not args.unfused:
-            line["variants"] = variants(scene, dgr, args, dev)
+            line["reference_operator_api"], line["variants"] = variants(scene, dgr, args, dev)
         if world == 1 and not args.no_cpu_baseline:
             line["cpu_baseline"] = cpu_baseline(scene.cloud, W, H, deg)
         print(json.dumps(line), flush=True)
@@ -393,38 +413,52 @@ def main():
 
 
 def variants(scene, dgr, args, dev):
-    """The default workload's step measured two more ways, shorter runs of the same loop:
-    through the reference's unchanged operator API (its model getters as PyTorch ops feeding
-    GaussianRasterizer, gaussian_renderer/__init__.py:53-93), and on the same cloud with every opacity
-    0.1 (the reference's initial opacity): nothing saturates early, the hard case for the blend kernels."""
-    out = {}
+    """The default workload's step measured three more ways, shorter runs of the same loop: through the
+    reference's unchanged operator API (its model getters as PyTorch ops feeding GaussianRasterizer,
+    gaussian_renderer/__init__.py:53-93), returned first; then, as a dict, on the same cloud with every opacity 0.1
+    (the reference's initial opacity: nothing saturates early, the hard case for the blend kernels) and on the
+    skewed 6M cloud with those opacities (the worst case for tile-load skew)."""
     steps, warmup = max(5, args.steps // 2), 3
     m = measure(scene, dgr, False, steps, warmup, stage_table=False)
-    out["reference_operator_api"] = {
-        "what": "activations as PyTorch ops (exp, sigmoid, normalize, cat) feeding GaussianRasterizer, as the reference calls it",
-        "render_ms": round(m["render_ms"], 3), "train_step_ms": round(1e3 * m["elapsed"] / steps, 3),
-        "render_Msplats_per_s": round(scene.P / (m["render_ms"] * 1e-3) / 1e6, 1), "steps": steps}
-    hard = Scene("c3w", dev, 0)
-    m = measure(hard, dgr, True, steps, warmup, stage_table=True)
-    n_inst = _instances(dgr, hard)
-    alg = algorithmic_bytes(hard.P, n_inst, hard.W, hard.H)
-    bwd_ms, fwd_ms = m["exact"]["blend_bwd"][0], m["exact"]["blend_fwd"][0]
-    source, counters = committed_counters("c3w")
-    out["c3w_opacity_0.1"] = {
-        "what": "the same cloud with every opacity 0.1 (scene/gaussian_model.py:139): no early termination",
-        "render_ms": round(m["render_ms"], 3), "train_step_ms": round(1e3 * m["elapsed"] / steps, 3),
-        "render_Msplats_per_s": round(hard.P / (m["render_ms"] * 1e-3) / 1e6, 1), "steps": steps,
-        "tile_instances": n_inst, "stage_ms": {k: round(v, 4) for k, v in m["stage_ms"].items()},
-        "blend_fwd": {"kernel_ms": round(fwd_ms, 4), "algorithmic_GBps": round(alg["blend_fwd"] / fwd_ms / 1e6, 1),
-                      "frac_of_hbm_peak": round(alg["blend_fwd"] / fwd_ms / 1e6 / HBM_PEAK_GBS, 4)},
-        "blend_bwd": {"kernel_ms": round(bwd_ms, 4), "algorithmic_GBps": round(alg["blend_bwd"] / bwd_ms / 1e6, 1),
-                      "frac_of_hbm_peak": round(alg["blend_bwd"] / bwd_ms / 1e6 / HBM_PEAK_GBS, 4),
-                      **limits("blend_bwd", bwd_ms, alg["blend_bwd"], counters, source)}}
-    return out
+    api = {
+        "what": "activations as PyTorch ops (exp, sigmoid, normalize, cat) feeding GaussianRasterizer, as the reference "
+                "calls it (gaussian_renderer/__init__.py:53-93): the step a user of the drop-in gets without changing a line",
+        "value": round(scene.P / (m["render_ms"] * 1e-3) / 1e6, 1), "unit": "Msplats/s",
+        "render_ms": round(m["render_ms"], 3), "train_step_ms": round(1e3 * m["elapsed"] / steps, 3), "steps": steps}
+    out = {}
+    for name, key, what in (
+            ("c3w", "c3w_opacity_0.1", "the same cloud with every opacity 0.1 (scene/gaussian_model.py:139): no early termination"),
+            ("c5w", "c5w_skew_opacity_0.1", "6M Gaussians, half of them in a hot spot, every opacity 0.1: tile-load skew "
+                                            "without early termination")):
+        hard = Scene(name, dev, 0)
+        m = measure(hard, dgr, True, steps, warmup, stage_table=True)
+        lists = _list_stats(dgr, hard)
+        n_inst = lists["instances"]
+        alg = algorithmic_bytes(hard.P, n_inst, hard.W, hard.H)
+        bwd_ms, fwd_ms = m["exact"]["blend_bwd"][0], m["exact"]["blend_fwd"][0]
+        source, counters = committed_counters(name)
+        out[key] = {
+            "what": what,
+            "render_ms": round(m["render_ms"], 3), "train_step_ms": round(1e3 * m["elapsed"] / steps, 3),
+            "render_Msplats_per_s": round(hard.P / (m["render_ms"] * 1e-3) / 1e6, 1), "steps": steps,
+            "lists": lists, "stage_ms": {k: round(v, 4) for k, v in m["stage_ms"].items()},
+            "blend_fwd": {"kernel_ms": round(fwd_ms, 4), "algorithmic_GBps": round(alg["blend_fwd"] / fwd_ms / 1e6, 1),
+                          "frac_of_hbm_peak": round(alg["blend_fwd"] / fwd_ms / 1e6 / HBM_PEAK_GBS, 4)},
+            "blend_bwd": {"kernel_ms": round(bwd_ms, 4), "algorithmic_GBps": round(alg["blend_bwd"] / bwd_ms / 1e6, 1),
+                          "frac_of_hbm_peak": round(alg["blend_bwd"] / bwd_ms / 1e6 / HBM_PEAK_GBS, 4),
+                          **limits("blend_bwd", bwd_ms, alg["blend_bwd"], counters, source)}}
+        del hard
+        torch.cuda.empty_cache()
+    return api, out
 
 
-def _instances(dgr, scene):
-    """Number of (tile, splat) instances of the benchmarked view (untimed)."""
+def _list_stats(dgr, scene):
+    """Measured statistics of the benchmarked view's tile lists, from one untimed forward: the number of
+    (tile, splat) instances, the longest and the mean list, how deep the lists are walked (per tile, the position of
+    the deepest splat any of its pixels blended: where its forward stops and its backward starts), and pixel-splat
+    pairs: `listed` = 256 per instance (what a kernel without culling or early termination would evaluate), and
+    `to_last_contributor` = the sum over pixels of the position of the pixel's last contributor (the entries a
+    pixel's backward walks, and what its forward walks at least)."""
     cam, model = scene.cam, scene.model
     with torch.no_grad():
         s = dgr.GaussianRasterizationSettings(
@@ -434,9 +468,21 @@ def _instances(dgr, scene):
             prefiltered=False, debug=False)
         st = dgr.rasterize_forward(s, model.get_xyz, model.get_opacity, shs=model.get_features,
                                    scales=model.get_scaling, rotations=model.get_rotation)
-        n = st.num_rendered
+        r = st.ranges.to(torch.int64)
+        length = r[:, 1] - r[:, 0]
+        H, W = st.H, st.W
+        gy, gx = (H + 15) // 16, (W + 15) // 16
+        nc = torch.zeros((gy * 16, gx * 16), dtype=torch.int64, device=length.device)
+        nc[:H, :W] = st.n_contrib.to(torch.int64)
+        depth = nc.reshape(gy, 16, gx, 16).amax(dim=(1, 3)).reshape(-1)
+        out = {"instances": int(st.num_rendered), "tiles": int(length.numel()),
+               "tile_list_length": {"max": int(length.max()), "mean": round(float(length.float().mean()), 1)},
+               "walked_depth_per_tile": {"max": int(depth.max()), "mean": round(float(depth.float().mean()), 1),
+                                         "share_of_walk_in_the_deepest_1pct_of_tiles":
+                                             round(float(depth.sort().values[-max(1, depth.numel() // 100):].sum() / depth.sum().clamp_min(1)), 4)},
+               "pixel_splat_pairs": {"listed": 256 * int(st.num_rendered), "to_last_contributor": int(nc.sum())}}
         del st
-        return n
+        return out
 
 
 def cpu_baseline(cloud, W, H, deg):

@@ -147,7 +147,7 @@ __device__ __forceinline__ void fill_my_share(const ShareFill& f) {
   if (f.vecs == 0) return;
   const size_t first = ((size_t)blockIdx.y * gridDim.x + blockIdx.x) * f.share;
   const size_t end = first + f.share < f.vecs ? first + f.share : f.vecs;
-  for (size_t i = first + threadIdx.x; i < end; i += 256) f.at[i] = make_uint4(0u, 0u, 0u, 0u);   // workgroups of 256
+  for (size_t i = first + threadIdx.x; i < end; i += blockDim.x) f.at[i] = make_uint4(0u, 0u, 0u, 0u);
 }
 
 inline size_t fill_share(size_t bytes, dim3 grid) {
@@ -447,102 +447,25 @@ __global__ void __launch_bounds__(256) blend_bwd_kernel(int W, int H, const uint
 
 
 // ---------------------------------------------------------------------------
-// backward, second formulation: the sums over pixels are deferred
+// backward with two pixels per lane
 // ---------------------------------------------------------------------------
-// blend_bwd_kernel reduces nine values over the wave's 64 pixels for every (quadrant, splat): eight LDS stores,
-// two wide loads, seven adds and eleven cross-lane steps per splat.  Here the walk (lane = pixel) only produces,
-// per splat, the two per-pixel factors everything else is linear in: u = dL/dG G and w = alpha T (the weight of
-// the splat's colour in the pixel), and parks them as two rows of 64 in LDS.  Every R splats the wave turns
-// round: LPS = 64 / R lanes take one splat each, a lane reads PPL = 64 / LPS of its pixels' u and w with one or
-// two 16-byte loads and forms the moments with the pixel offsets and the pixels' dL/dcolour (which the lane
-// holds in registers: its pixels are the same every round), so the sums over pixels run inside the lane; what
-// is left across lanes is a halving exchange over the LPS lanes of a splat (each step sends half of the values
-// one way and half the other, so 8 values over 8 lanes take 12 + 6 + 3 operations and end with value i on lane
-// i).  Per splat that is two LDS stores and about thirteen vector instructions instead of eight stores and
-// thirty.  With ACC the splat's nine sums then go into a per-tile accumulator in LDS (one row per staged
-// splat, shared by the four quadrants), which the workgroup adds to the global rows once per batch, sixteen
-// lanes to a row: one atomic request per (tile, splat) instead of one per (quadrant, splat), and none inside the
-// walk.
-template <int R>
-struct RowShape {
-  static constexpr int kLanesPerSplat = 64 / R;          // 8 or 16
-  static constexpr int kPixelsPerLane = 64 / kLanesPerSplat;   // 8 or 4: the lane's piece of one pixel row
-  static_assert(R == 4 || R == 8, "rows per round: 4 or 8");
+// blend_bwd_kernel spends a (wave, splat) turn mostly waiting: three or four LDS round trips and two dozen
+// dependent cross-lane steps in a row for some sixty vector instructions, at the hardware's limit of eight waves
+// per SIMD.  Here a wave owns a 16 x 8 half tile instead of an 8 x 8 quadrant, a lane the pixels (x, y) and
+// (x + 8, y): two independent chains of arithmetic per turn (real instruction-level parallelism: the two pixels
+// share nothing but the splat), ONE set of LDS reads, ONE reduction and ONE atomic for 128 pixels, and because
+// the two pixels have the same dy, three of the six geometric moments of the pair are products of the other
+// three with dy.  The price is coarser culling: a splat that reaches one of the two quadrants costs both.
+// A workgroup is two waves and stages 128 splats per batch.
+constexpr int kPairBatch = 128;
+
+struct StagedPair {
+  float4 geo[kPairBatch];    // x, y, -log2e/2 A, -log2e B
+  float4 col[kPairBatch];    // -log2e/2 C, opacity, r, g
+  float2 tail[kPairBatch];   // blue, index bits
 };
 
-constexpr int kAccWords = 9;
-
-template <int CTRL>
-__device__ __forceinline__ float dpp_move(float v) {
-  return __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v), CTRL, 0xf, 0xf, false));
-}
-
-// One step of the halving exchange: of 2 n values, a lane whose `upper` is false keeps v[0..n) and receives its
-// partner's, the partner (upper true) keeps v[n..2n); both send the half they give up.
-template <int CTRL, int N>
-__device__ __forceinline__ void halve(float* v, bool upper) {
-#pragma unroll
-  for (int i = 0; i < N; i++) {
-    const float keep = upper ? v[i + N] : v[i];
-    const float send = upper ? v[i] : v[i + N];
-    v[i] = keep + dpp_move<CTRL>(send);
-  }
-}
-
-constexpr int kDppXor1 = 0xB1, kDppXor2 = 0x4E, kDppHalfMirror = 0x141, kDppMirror = 0x140;
-
-// Sums v[0..8) over the kLanesPerSplat lanes of a splat; returns the total of ONE of them, word_of_lane() says which.
-template <int LPS>
-__device__ __forceinline__ float exchange_sum(float* v, int lane) {
-  if (LPS == 16) {
-    halve<kDppMirror, 4>(v, (lane & 8) != 0);          // partner 15 - k
-    halve<kDppHalfMirror, 2>(v, (lane & 4) != 0);      // partner 7 - k of the same eight
-    halve<kDppXor1, 1>(v, (lane & 1) != 0);
-    return v[0] + dpp_move<kDppXor2>(v[0]);            // both lanes of the last pair hold the total
-  } else {
-    halve<kDppHalfMirror, 4>(v, (lane & 4) != 0);
-    halve<kDppXor1, 2>(v, (lane & 1) != 0);
-    halve<kDppXor2, 1>(v, (lane & 2) != 0);
-    return v[0];
-  }
-}
-
-template <int LPS>
-__device__ __forceinline__ int word_of_lane(int lane) {
-  return LPS == 16 ? (((lane >> 3) & 1) << 2) | (((lane >> 2) & 1) << 1) | (lane & 1)
-                   : (lane & 4) | ((lane & 1) << 1) | ((lane >> 1) & 1);
-}
-
-template <int LPS>
-__device__ __forceinline__ float plain_sum(float v) {
-  v = dpp_add<kDppXor1>(v);
-  v = dpp_add<kDppXor2>(v);
-  v = dpp_add<kDppHalfMirror>(v);
-  if (LPS == 16) v = dpp_add<kDppMirror>(v);
-  return v;
-}
-
-__device__ __forceinline__ void store_row_pair(unsigned base, float u, float w) {
-  asm volatile(
-      "s_mov_b32 m0, %2\n\t"
-      "s_nop 0\n\t"
-      "ds_write_addtid_b32 %0 offset:0\n\t"
-      "ds_write_addtid_b32 %1 offset:256"
-      :
-      : "v"(u), "v"(w), "s"(base)
-      : "m0", "memory");
-}
-
-template <bool WITH_IDS>
-struct StagedRows {
-  float4 geo[kBatch];    // x, y, -log2e/2 A, -log2e B
-  float4 col[kBatch];    // -log2e/2 C, opacity, r, g
-  float blue[kBatch];
-  uint32_t id[WITH_IDS ? kBatch : 1];
-};
-
-template <int R, bool ACC>
-__global__ void __launch_bounds__(256) blend_bwd_rows_kernel(int W, int H, const uint2* __restrict__ ranges,
+__global__ void __launch_bounds__(128) blend_bwd_pair_kernel(int W, int H, const uint2* __restrict__ ranges,
                                                              const uint32_t* __restrict__ point_list,
                                                              const uint4* __restrict__ records,
                                                              const float* __restrict__ bg,
@@ -551,199 +474,116 @@ __global__ void __launch_bounds__(256) blend_bwd_rows_kernel(int W, int H, const
                                                              const float* __restrict__ dL_dpix,
                                                              float* __restrict__ dL_dsplat,
                                                              uint8_t* __restrict__ touched, ShareFill fill) {
-  constexpr int LPS = RowShape<R>::kLanesPerSplat, PPL = RowShape<R>::kPixelsPerLane;
-  __shared__ __align__(16) StagedRows<!ACC> s_splat;
-  __shared__ unsigned long long s_mask[4][4];
-  __shared__ int s_last[4];
-  __shared__ __align__(16) float s_rows[4][R * 128];      // per wave and row: 64 u, then 64 w
-  __shared__ float s_acc[ACC ? kBatch * kAccWords : 1];   // per staged splat: its nine sums over the tile
+  __shared__ __align__(16) StagedPair s_splat;
+  __shared__ unsigned long long s_mask[2][2];     // [half tile][staging wave]
+  __shared__ int s_last[2];
+  __shared__ __align__(16) float s_red[2][8 * kRedStride];
 
-  const Pixel px = my_pixel(W, H);
-  const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
-  const float pxf = (float)px.x, pyf = (float)px.y;
+  const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;     // wave 0: rows 0..7 of the tile, wave 1: rows 8..15
+  const int x0 = blockIdx.x * GSR_TILE_X + (lane & 7), x1 = x0 + 8, y = blockIdx.y * GSR_TILE_Y + wave * 8 + (lane >> 3);
+  const bool in0 = x0 < W && y < H, in1 = x1 < W && y < H;
+  const float x0f = (float)x0, x1f = (float)x1, yf = (float)y;
   const float tx0 = (float)(blockIdx.x * GSR_TILE_X), ty0 = (float)(blockIdx.y * GSR_TILE_Y);
   const uint2 range = ranges[blockIdx.y * gridDim.x + blockIdx.x];
   const int total = (int)(range.y - range.x);
 
-  const size_t pix = (size_t)px.y * W + px.x, plane = (size_t)W * H;
-  const float Tf = px.inside ? final_T[pix] : 0.f;
-  const int last = px.inside ? (int)n_contrib[pix] : 0;
-  float dp0 = 0.f, dp1 = 0.f, dp2 = 0.f;
-  if (px.inside) { dp0 = dL_dpix[pix]; dp1 = dL_dpix[plane + pix]; dp2 = dL_dpix[2 * plane + pix]; }
-  const float Tf_bg = Tf * (bg[0] * dp0 + bg[1] * dp1 + bg[2] * dp2);
-  int wl = last;
+  const size_t plane = (size_t)W * H, pix0 = (size_t)y * W + x0, pix1 = pix0 + 8;
+  const float Tf0 = in0 ? final_T[pix0] : 0.f, Tf1 = in1 ? final_T[pix1] : 0.f;
+  const int last0 = in0 ? (int)n_contrib[pix0] : 0, last1 = in1 ? (int)n_contrib[pix1] : 0;
+  float r0 = 0.f, g0 = 0.f, b0 = 0.f, r1 = 0.f, g1 = 0.f, b1 = 0.f;      // dL/dcolour of the two pixels
+  if (in0) { r0 = dL_dpix[pix0]; g0 = dL_dpix[plane + pix0]; b0 = dL_dpix[2 * plane + pix0]; }
+  if (in1) { r1 = dL_dpix[pix1]; g1 = dL_dpix[plane + pix1]; b1 = dL_dpix[2 * plane + pix1]; }
+  const float bgr = bg[0], bgg = bg[1], bgb = bg[2];
+  const float Tf_bg0 = Tf0 * (bgr * r0 + bgg * g0 + bgb * b0), Tf_bg1 = Tf1 * (bgr * r1 + bgg * g1 + bgb * b1);
+  int wl = max(last0, last1);
 #pragma unroll
   for (int o = 32; o > 0; o >>= 1) wl = max(wl, __shfl_xor(wl, o));
   if (lane == 0) s_last[wave] = wl;
   __syncthreads();
   const int wave_last = __builtin_amdgcn_readfirstlane(wl);
-  const int tile_last = max(max(s_last[0], s_last[1]), max(s_last[2], s_last[3]));
+  const int tile_last = max(s_last[0], s_last[1]);
   if (tile_last == 0 || total == 0) { fill_my_share(fill); return; }
 
-  // The lane's part in the turn-round: splat `my_s` of the round, and PPL pixels of one pixel row of the quadrant.
-  // With 8 pixels per lane they come as two 16-byte loads; lanes of odd splats take the two halves in the
-  // other order, which keeps the sixteen lanes of a load phase on 64 distinct banks (rows are 128 words apart).
-  const int my_s = lane / LPS, my_g = lane % LPS;
-  const int my_row = PPL == 8 ? my_g : (my_g >> 1);
-  const int first_col = PPL == 8 ? ((my_s & 1) ? 4 : 0) : 4 * (my_g & 1);
-  const int second_col = first_col ^ 4;                         // PPL == 8 only
-  const int qx0 = blockIdx.x * GSR_TILE_X + (wave & 1) * 8, qy = blockIdx.y * GSR_TILE_Y + (wave >> 1) * 8 + my_row;
-  float dq0[PPL], dq1[PPL], dq2[PPL];                           // dL/dcolour of the lane's pixels, in load order
-#pragma unroll
-  for (int k = 0; k < PPL; k++) {
-    const int x = qx0 + (k < 4 ? first_col + k : second_col + (k - 4));
-    const bool in = x < W && qy < H;
-    const size_t at = (size_t)qy * W + x;
-    dq0[k] = in ? dL_dpix[at] : 0.f;
-    dq1[k] = in ? dL_dpix[plane + at] : 0.f;
-    dq2[k] = in ? dL_dpix[2 * plane + at] : 0.f;
-  }
-  const float first_x = (float)(qx0 + first_col), second_x = (float)(qx0 + second_col), row_y = (float)qy;
-  const float4* const my_u = reinterpret_cast<const float4*>(s_rows[wave] + my_s * 128 + my_row * 8);
-  const int my_word = word_of_lane<LPS>(lane);
-  const bool reports = LPS == 8 || (lane & 2) == 0;             // with 16 lanes per splat two lanes end with each total
-
+  float T0 = Tf0, T1 = Tf1, behind0 = 0.f, behind1 = 0.f;
   typedef __attribute__((address_space(3))) float lds_float;
-  const unsigned rows_base = __builtin_amdgcn_readfirstlane((unsigned)(uintptr_t)(lds_float*)s_rows[wave]);
-  int rowslot = 0;       // lane r: the staged slot of row r of the current round
-  int rows = 0;          // rows parked in the current round (wave-uniform)
+  const unsigned red_base = __builtin_amdgcn_readfirstlane((unsigned)(uintptr_t)(lds_float*)s_red[wave]);
+  const int my_row = lane >> 3, my_first = (my_row & 2) ? 32 : 0, my_seg = 4 * (lane & 7);
+  const float4* const red_lo = reinterpret_cast<const float4*>(s_red[wave] + my_row * kRedStride + my_first + my_seg);
+  const float4* const red_hi = reinterpret_cast<const float4*>(s_red[wave] + my_row * kRedStride + (my_first ^ 32) + my_seg);
 
-  float T = Tf, acc_dp = 0.f;     // acc_dp: colour composited behind the current splat, dotted with dL/dcolour
-
-  // rows [0, n) of the round -> sums per splat -> accumulator / global rows
-  auto turn_round = [&](int n) {
-    const int j = __builtin_amdgcn_ds_bpermute(my_s << 2, rowslot);
-    const float4 geo = s_splat.geo[j];
-    float u[PPL], w[PPL];
-    {
-      const float4 a = my_u[first_col >> 2], b = my_u[16 + (first_col >> 2)];
-      u[0] = a.x; u[1] = a.y; u[2] = a.z; u[3] = a.w;
-      w[0] = b.x; w[1] = b.y; w[2] = b.z; w[3] = b.w;
-      if (PPL == 8) {
-        const float4 c = my_u[second_col >> 2], d = my_u[16 + (second_col >> 2)];
-        u[PPL - 4] = c.x; u[PPL - 3] = c.y; u[PPL - 2] = c.z; u[PPL - 1] = c.w;
-        w[PPL - 4] = d.x; w[PPL - 3] = d.y; w[PPL - 2] = d.z; w[PPL - 1] = d.w;
-      }
-    }
-    const float dxa = geo.x - first_x, dxb = geo.x - second_x, dy = geo.y - row_y;
-    float s0 = 0.f, s1 = 0.f, s3 = 0.f, c0 = 0.f, c1 = 0.f, c2 = 0.f;
-#pragma unroll
-    for (int k = 0; k < PPL; k++) {
-      const float dx = (k < 4 ? dxa : dxb) - (float)(k & 3);
-      const float t = u[k] * dx;
-      s0 += u[k];
-      s1 += t;
-      s3 = fmaf(t, dx, s3);
-      c0 = fmaf(w[k], dq0[k], c0);
-      c1 = fmaf(w[k], dq1[k], c1);
-      c2 = fmaf(w[k], dq2[k], c2);
-    }
-    const float m2 = dy * s0;
-    float v[8] = {s0, s1, m2, s3, dy * s1, dy * m2, c0, c1};      // GSR_GRAD_WORDS order
-    const float mine = exchange_sum<LPS>(v, lane);
-    const float ninth = plain_sum<LPS>(c2);
-    const bool live = my_s < n;
-    if (ACC) {
-      if (live && reports) atomicAdd(&s_acc[j * kAccWords + my_word], mine);
-      if (live && my_g == 0) atomicAdd(&s_acc[j * kAccWords + 8], ninth);
-    } else {
-      float* const row = dL_dsplat + (size_t)s_splat.id[j] * GSR_GRAD_WORDS;
-      if (live && reports) atomicAdd(row + my_word, mine);
-      if (live && my_g == 0) atomicAdd(row + 8, ninth);
-    }
-  };
-
-  // the accumulator's rows of batch `b` -> global rows, sixteen lanes to a row; leaves them zero
-  auto flush_batch = [&](int b) {
-#pragma unroll 4
-    for (int it = 0; it < 16; it++) {
-      const int slot = wave * 64 + it * 4 + (lane >> 4), word = lane & 15;
-      const int s = b * kBatch + slot;
-      if (word < kAccWords && s < total && s < tile_last) {
-        float* const at = &s_acc[slot * kAccWords + word];
-        const float v = *at;
-        if (v != 0.0f) {
-          *at = 0.0f;
-          atomicAdd(dL_dsplat + (size_t)point_list[range.x + s] * GSR_GRAD_WORDS + word, v);
-        }
-      }
-    }
-  };
-
-  if (ACC)
-    for (int i = threadIdx.x; i < kBatch * kAccWords; i += 256) s_acc[i] = 0.0f;
-
-  const int first_batch = (tile_last - 1) / kBatch;
-  for (int b = first_batch; b >= 0; b--) {
+  for (int b = (tile_last - 1) / kPairBatch; b >= 0; b--) {
     __syncthreads();
-    if (ACC && b != first_batch) flush_batch(b + 1);
-    const int s = b * kBatch + (int)threadIdx.x;
+    const int s = b * kPairBatch + (int)threadIdx.x;
     unsigned qm = 0u;
     if (s < total && s < tile_last) {
       const uint32_t g = point_list[range.x + s];
       const uint4* rec = records + (size_t)g * 4;
-      const uint4 r0 = rec[0], r1 = rec[1], r2 = rec[2];
-      const float sx = __uint_as_float(r0.x), sy = __uint_as_float(r0.y);
-      qm = quadrant_mask(sx, sy, __uint_as_float(r0.z), __uint_as_float(r0.w), __uint_as_float(r1.x),
-                         __uint_as_float(r1.y), __uint_as_float(r1.z), __uint_as_float(r1.w), tx0, ty0);
-      s_splat.geo[threadIdx.x] = make_float4(sx, sy, -0.5f * kLog2e * __uint_as_float(r1.x), -kLog2e * __uint_as_float(r1.y));
-      s_splat.col[threadIdx.x] = make_float4(-0.5f * kLog2e * __uint_as_float(r1.z), __uint_as_float(r1.w),
-                                             __uint_as_float(r2.x), __uint_as_float(r2.y));
-      s_splat.blue[threadIdx.x] = __uint_as_float(r2.z);
-      if (!ACC) s_splat.id[threadIdx.x] = g;
+      const uint4 q0 = rec[0], q1 = rec[1], q2 = rec[2];
+      const float sx = __uint_as_float(q0.x), sy = __uint_as_float(q0.y);
+      qm = quadrant_mask(sx, sy, __uint_as_float(q0.z), __uint_as_float(q0.w), __uint_as_float(q1.x),
+                         __uint_as_float(q1.y), __uint_as_float(q1.z), __uint_as_float(q1.w), tx0, ty0);
+      s_splat.geo[threadIdx.x] = make_float4(sx, sy, -0.5f * kLog2e * __uint_as_float(q1.x), -kLog2e * __uint_as_float(q1.y));
+      s_splat.col[threadIdx.x] = make_float4(-0.5f * kLog2e * __uint_as_float(q1.z), __uint_as_float(q1.w),
+                                             __uint_as_float(q2.x), __uint_as_float(q2.y));
+      s_splat.tail[threadIdx.x] = make_float2(__uint_as_float(q2.z), __uint_as_float(g));
       if (touched != nullptr && qm != 0u) touched[g] = 1;
     }
-#pragma unroll
-    for (int q = 0; q < 4; q++) {
-      const unsigned long long m = __ballot((qm >> q) & 1u);
-      if (lane == 0) s_mask[q][wave] = m;
+    {
+      const unsigned long long top = __ballot((qm & 3u) != 0u), bottom = __ballot((qm & 12u) != 0u);
+      if (lane == 0) { s_mask[0][wave] = top; s_mask[1][wave] = bottom; }
     }
     __syncthreads();
 
-    if (b * kBatch >= wave_last) continue;   // nothing this deep for this quadrant
-    for (int sw = 3; sw >= 0; sw--) {
-      unsigned long long m = lds_mask(&s_mask[px.quad][sw]);
-      const int room = wave_last - (b * kBatch + sw * 64);
+    if (b * kPairBatch >= wave_last) continue;   // nothing this deep for this half tile
+    for (int sw = 1; sw >= 0; sw--) {
+      unsigned long long m = lds_mask(&s_mask[wave][sw]);
+      const int room = wave_last - (b * kPairBatch + sw * 64);
       if (room <= 0) continue;
       if (room < 64) m &= (1ull << room) - 1ull;
       while (m) {
         const int bit = 63 - __clzll((long long)m);
         m &= ~(1ull << bit);
         const int j = sw * 64 + bit;
-        const int pos = b * kBatch + j;
+        const int pos = b * kPairBatch + j;
         const float4 geo = s_splat.geo[j], col = s_splat.col[j];
-        const float dx = geo.x - pxf, dy = geo.y - pyf;
-        const float p = gauss_exponent(geo.z, geo.w, col.x, dx, dy);
-        float oG = col.y * __builtin_amdgcn_exp2f(p);
-        const bool hit = (p <= 0.0f) & (oG >= GSR_ALPHA_MIN) & (pos < last);
-        if (__ballot(hit) == 0ull) continue;
-        oG = hit ? oG : 0.0f;
-        const float alpha = __builtin_amdgcn_fmed3f(oG, 0.0f, GSR_ALPHA_MAX);
-        const float inv = __builtin_amdgcn_rcpf(1.0f - alpha);     // alpha == 0: exactly 1
-        T = T * inv;                                               // transmittance in front of the splat
-        // dL/dalpha = (c - behind) . dL/dcolour T - T_final / (1 - alpha) bg . dL/dcolour, the colours only
-        // through their dot products with the pixel's dL/dcolour
-        const float cd = fmaf(s_splat.blue[j], dp2, fmaf(col.w, dp1, col.z * dp0));
-        const float d = cd - acc_dp;
-        const float dL_dalpha = fmaf(d, T, -(Tf_bg * inv));
-        acc_dp = fmaf(alpha, d, acc_dp);                           // alpha c + (1 - alpha) behind
-        store_row_pair(rows_base + (unsigned)rows * 512u, dL_dalpha * oG, alpha * T);
-        rowslot = lane == rows ? j : rowslot;
-        if (++rows == R) {
-          turn_round(R);
-          rows = 0;
-        }
+        // the same subtractions and the same exponent as the forward's, per pixel
+        const float dxa = geo.x - x0f, dxb = geo.x - x1f, dy = geo.y - yf;
+        const float pa = gauss_exponent(geo.z, geo.w, col.x, dxa, dy), pb = gauss_exponent(geo.z, geo.w, col.x, dxb, dy);
+        float oGa = col.y * __builtin_amdgcn_exp2f(pa), oGb = col.y * __builtin_amdgcn_exp2f(pb);
+        const bool hita = (pa <= 0.0f) & (oGa >= GSR_ALPHA_MIN) & (pos < last0);
+        const bool hitb = (pb <= 0.0f) & (oGb >= GSR_ALPHA_MIN) & (pos < last1);
+        if (__ballot(hita | hitb) == 0ull) continue;
+        oGa = hita ? oGa : 0.0f;
+        oGb = hitb ? oGb : 0.0f;
+        const float alphaa = __builtin_amdgcn_fmed3f(oGa, 0.0f, GSR_ALPHA_MAX), alphab = __builtin_amdgcn_fmed3f(oGb, 0.0f, GSR_ALPHA_MAX);
+        const float inva = __builtin_amdgcn_rcpf(1.0f - alphaa), invb = __builtin_amdgcn_rcpf(1.0f - alphab);
+        T0 *= inva;
+        T1 *= invb;
+        const float2 bi = s_splat.tail[j];
+        const float da = fmaf(bi.x, b0, fmaf(col.w, g0, col.z * r0)) - behind0;
+        const float db = fmaf(bi.x, b1, fmaf(col.w, g1, col.z * r1)) - behind1;
+        const float ua = fmaf(da, T0, -(Tf_bg0 * inva)) * oGa, ub = fmaf(db, T1, -(Tf_bg1 * invb)) * oGb;
+        behind0 = fmaf(alphaa, da, behind0);
+        behind1 = fmaf(alphab, db, behind1);
+        const float wa = alphaa * T0, wb = alphab * T1;
+        // the pair's nine contributions; dy is common to the two pixels
+        const float u = ua + ub;
+        const float uxa = ua * dxa, uxb = ub * dxb;
+        const float ux = uxa + uxb;
+        const float uxx = fmaf(uxb, dxb, uxa * dxa);
+        const float uy = u * dy;
+        store_rows_addtid(red_base, u, ux, uy, uxx, ux * dy, uy * dy, fmaf(wb, r1, wa * r0), fmaf(wb, g1, wa * g0));
+        const float4 a0 = *red_lo, a1 = *red_hi;
+        float v = ((a0.x + a0.y) + (a0.z + a0.w)) + ((a1.x + a1.y) + (a1.z + a1.w));
+        float v8 = fmaf(wb, b1, wa * b0);
+        v = dpp_add<0xB1>(v); v = dpp_add<0x4E>(v); v = dpp_add<0x141>(v);
+        v8 = dpp_add<0xB1>(v8); v8 = dpp_add<0x4E>(v8); v8 = dpp_add<0x141>(v8); v8 = dpp_add<0x140>(v8);
+        v8 = sum_across_rows(v8);
+        const bool ninth = lane == 1;
+        if ((lane & 7) == 0 || ninth)
+          atomicAdd(dL_dsplat + (size_t)__float_as_uint(bi.y) * GSR_GRAD_WORDS + (ninth ? 8 : (lane >> 3)), ninth ? v8 : v);
       }
     }
-    // the staged splats change with the next batch: what is parked refers to them by slot
-    if (rows) {
-      turn_round(rows);
-      rows = 0;
-    }
-  }
-  if (ACC) {
-    __syncthreads();
-    flush_batch(0);
   }
   fill_my_share(fill);
 }
@@ -789,17 +629,14 @@ int launch_blend_bwd(int W, int H, const uint32_t* ranges, const uint32_t* point
   const ShareFill fill = share_fill(zero_fill, zero_fill_bytes, grid);
   typedef void (*Kernel)(int, int, const uint2*, const uint32_t*, const uint4*, const float*, const float*, const uint32_t*,
                          const float*, float*, uint8_t*, ShareFill);
-  static const Kernel kernel = [] {
-    // GSR_BLEND_BWD picks the formulation, for measurements of one against the other
+  // GSR_BLEND_BWD=lanes: the one-pixel-per-lane formulation (four waves per tile), for measurements of one
+  // against the other and as an independent implementation in the tests
+  static const bool lanes = [] {
     const char* e = getenv("GSR_BLEND_BWD");
-    const std::string v = e ? e : "";
-    if (v == "lanes") return (Kernel)blend_bwd_kernel;
-    if (v == "rows8") return (Kernel)blend_bwd_rows_kernel<8, false>;
-    if (v == "rows4") return (Kernel)blend_bwd_rows_kernel<4, false>;
-    if (v == "rows8acc") return (Kernel)blend_bwd_rows_kernel<8, true>;
-    if (v == "rows4acc") return (Kernel)blend_bwd_rows_kernel<4, true>;
-    return (Kernel)blend_bwd_kernel;
+    return e && std::string(e) == "lanes";
   }();
+  const Kernel kernel = lanes ? (Kernel)blend_bwd_kernel : (Kernel)blend_bwd_pair_kernel;
+  if (kernel == (Kernel)blend_bwd_pair_kernel) block = dim3(128);
   if (start || stop)
     hipExtLaunchKernelGGL(kernel, grid, block, 0, (hipStream_t)stream, start, stop, 0, W, H, (const uint2*)ranges,
                           point_list, (const uint4*)records, bg, final_T, n_contrib, dL_dpix, dL_dsplat, touched, fill);

@@ -19,7 +19,7 @@ from collections import defaultdict
 sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
 from summarize_rocprof import short  # noqa: E402
 
-STAGE_OF = {"blend_bwd_kernel": "blend_bwd", "blend_fwd_kernel": "blend_fwd", "preprocess_fwd_kernel": "preprocess_fwd",
+STAGE_OF = {"blend_bwd_kernel": "blend_bwd", "blend_bwd_pair_kernel": "blend_bwd", "blend_fwd_kernel": "blend_fwd", "preprocess_fwd_kernel": "preprocess_fwd",
             "preprocess_bwd_kernel": "preprocess_bwd", "loss_fwd_kernel": "loss_fwd", "loss_bwd_kernel": "loss_bwd"}
 
 
