@@ -252,7 +252,7 @@ def measure(scene, dgr, fused, steps, warmup, use_dist=False, dp_grads=False, op
     render_ms = sum(a.elapsed_time(b) for a, b in fwd_events) / len(fwd_events)
     radii = state["out"]["radii"]
     return {"elapsed": elapsed, "render_ms": render_ms, "exact": exact, "stage_ms": stage_ms,
-            "visible": int((radii > 0).sum().item()), "grad_scale": state["grad_scale"]}
+            "visible": int((radii > 0).sum().item()), "grad_scale": state["grad_scale"], "mean_loss": state["mean_loss"]}
 
 
 def main():
@@ -401,6 +401,8 @@ def main():
                           "GBps": round(28 * n_params / (adam_ms * 1e-3) / 1e9, 1)},
             "gradient_exchange": "all-reduce of all gradients inside the timed step" if args.dp_grads
                                  else "none (the mean loss, one scalar, once per timed region)",
+            "communicator": {"backend": dist.get_backend(), "ranks": dist.get_world_size()} if use_dist else None,
+            "mean_loss_over_ranks": m["mean_loss"],
         }
         if world == 1 and args.workload == "c3" and not args.no_variants and not args.unfused:
             line["reference_operator_api"], line["variants"] = variants(scene, dgr, args, dev)

@@ -6,7 +6,7 @@ learning rate each and ``eps = 1e-15`` (``scene/gaussian_model.py:154-163``,
 (``:164-175``, ``utils/general_utils.py:29-62``).  Here the update of all six
 tensors is ONE fused HIP launch (``gsr_adam_step``), and, when several ranks
 each render their own view of a replicated model, their gradients meet in one
-flat buffer that is all-reduced once over RCCL before the step.  There is no
+flat buffer that is summed over the ranks (reduce-scatter + all-gather over RCCL) before the step.  There is no
 CPU path for the update: the parameters must live on the GPU.
 """
 from __future__ import annotations
@@ -60,10 +60,52 @@ class OptimizationParams:
     rotation_lr: float = 0.001
 
 
+EXCHANGES = ("scatter_gather", "direct", "all_reduce")
+
+
+def _sum_flat_over_ranks(flat: torch.Tensor, group, method: str) -> None:
+    """In place: ``flat`` (1-D fp32, the same length on every rank) becomes its sum over the ranks of ``group``.
+
+    ``scatter_gather`` (the default): reduce-scatter, then all-gather.  Rank r ends the first step with the sum of
+    slice r of every rank's buffer and the second hands the slices round: each rank sends and receives 2 (n-1)/n
+    of the buffer, spread over its links to all n-1 peers, where one ring would push the same bytes through one
+    link (8 GPUs joined point to point by 7 xGMI links each; 236 MB of gradients at a million Gaussians).
+    ``direct``: the same two steps spelled out with point-to-point traffic only, an all-to-all of the slices,
+    a local sum, an all-gather: no ring even if the library would build one for a reduce-scatter.
+    ``all_reduce``: one collective, the library's choice of algorithm.
+    The first two need the length to be a multiple of the number of ranks (a GradArena pads for that); otherwise
+    the call falls back to ``all_reduce``.  ``gloo`` only ever sees host tensors."""
+    if method not in EXCHANGES:
+        raise ValueError(f"exchange method must be one of {EXCHANGES}")
+    world = dist.get_world_size(group)
+    if world <= 1:
+        return
+    work = flat
+    on_host = dist.get_backend(group) == "gloo" and flat.is_cuda
+    if on_host:
+        work = flat.cpu()
+    n = work.numel()
+    if method == "all_reduce" or n % world != 0:
+        dist.all_reduce(work, op=dist.ReduceOp.SUM, group=group)
+    else:
+        piece = n // world
+        if method == "scatter_gather":
+            mine = torch.empty((piece,), dtype=work.dtype, device=work.device)
+            dist.reduce_scatter_tensor(mine, work, op=dist.ReduceOp.SUM, group=group)
+        else:
+            theirs = torch.empty_like(work)                         # slice `rank` of every rank's buffer
+            dist.all_to_all_single(theirs, work, group=group)
+            mine = theirs.view(world, piece).sum(dim=0)
+        dist.all_gather_into_tensor(work, mine, group=group)
+    if on_host:
+        flat.copy_(work)
+
+
 class GradArena:
     """One flat fp32 buffer holding the gradients of all parameter tensors back to back (each
-    start 16-byte aligned), with a view per tensor.  Backward passes write into the views, the
-    data-parallel exchange is a single all-reduce of ``flat``, and the optimiser reads the views."""
+    start 16-byte aligned, the whole padded to a multiple of 1024 floats so that it splits evenly over
+    any power-of-two number of ranks), with a view per tensor.  Backward passes write into the views, the
+    data-parallel exchange works on ``flat`` as a whole, and the optimiser reads the views."""
 
     def __init__(self, params: Dict[str, torch.Tensor]):
         self.offsets, total = {}, 0
@@ -71,7 +113,7 @@ class GradArena:
             self.offsets[name] = total
             total += (p.numel() + 3) // 4 * 4
         first = next(iter(params.values()))
-        self.flat = torch.zeros((total,), dtype=torch.float32, device=first.device)
+        self.flat = torch.zeros(((total + 1023) // 1024 * 1024,), dtype=torch.float32, device=first.device)
         self.views = {name: self.flat[o:o + params[name].numel()].view_as(params[name])
                       for name, o in self.offsets.items()}
 
@@ -83,8 +125,9 @@ class GradArena:
     def zero_(self) -> None:
         self.flat.zero_()
 
-    def all_reduce(self, group=None, average: bool = True) -> float:
-        """Sums the gradients over the ranks of ``group`` in one collective and returns the factor the
+    def all_reduce(self, group=None, average: bool = True, method: str = "scatter_gather") -> float:
+        """Sums the gradients over the ranks of ``group`` (``method``: see _sum_flat_over_ranks; two collectives on
+        the one flat buffer by default) and returns the factor the
         optimiser step still has to apply: 1 / world size when every rank back-propagated its own
         un-normalised loss (``average``, the default: sum -> mean over ranks), 1.0 when the losses were
         already scaled so that their sum over ranks IS the wanted gradient (``average=False``: what
@@ -93,27 +136,32 @@ class GradArena:
         if not (dist.is_available() and dist.is_initialized()):
             return 1.0
         world = dist.get_world_size(group)
-        if world > 1:
-            if dist.get_backend(group) == "gloo" and self.flat.is_cuda:
-                host = self.flat.cpu()                      # gloo only ever sees host tensors
-                dist.all_reduce(host, op=dist.ReduceOp.SUM, group=group)
-                self.flat.copy_(host)
-            else:
-                dist.all_reduce(self.flat, op=dist.ReduceOp.SUM, group=group)
+        _sum_flat_over_ranks(self.flat, group, method)
         return 1.0 / world if average else 1.0
 
 
-def all_reduce_gradients(params: Dict[str, torch.Tensor], group=None, average: bool = True) -> float:
-    """Sums ``param.grad`` of every tensor over the ranks, all collectives in flight together
-    (the 45-coefficient SH gradient is 3/4 of the bytes; coalescing the small ones buys nothing
-    next to it), and returns the factor left for the optimiser step to apply: 1 / world size, or
-    1.0 with ``average=False`` (losses already normalised over all ranks' views, as
-    ``multiview_step`` does; see GradArena.all_reduce).  For gradients that already sit in a
-    GradArena use its single-collective ``all_reduce`` instead."""
+def all_reduce_gradients(params: Dict[str, torch.Tensor], group=None, average: bool = True,
+                         method: str = "all_reduce") -> float:
+    """Sums ``param.grad`` of every tensor over the ranks and returns the factor left for the optimiser step to
+    apply: 1 / world size, or 1.0 with ``average=False`` (losses already normalised over all ranks' views, as
+    ``multiview_step`` does; see GradArena.all_reduce).  ``method="all_reduce"``: one collective per tensor, all in
+    flight together (the 45-coefficient SH gradient is 3/4 of the bytes; coalescing the small ones buys nothing
+    next to it).  ``"scatter_gather"`` / ``"direct"``: the gradients are packed into one flat buffer, exchanged as
+    GradArena does, and unpacked (two extra copies of the gradients; gradients that already sit in a GradArena
+    skip them: use its ``all_reduce``)."""
     if not (dist.is_available() and dist.is_initialized()):
         return 1.0
     world = dist.get_world_size(group)
-    if world > 1:
+    if world > 1 and method != "all_reduce":
+        have = {k: p for k, p in params.items() if p.grad is not None}
+        if have:
+            arena = GradArena({k: p.grad for k, p in have.items()})
+            for k, p in have.items():
+                arena.views[k].copy_(p.grad)
+            _sum_flat_over_ranks(arena.flat, group, method)
+            for k, p in have.items():
+                p.grad.copy_(arena.views[k])
+    elif world > 1:
         host_side = dist.get_backend(group) == "gloo"
         pending = []
         for p in params.values():

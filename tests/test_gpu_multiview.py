@@ -1,8 +1,14 @@
 """Two processes on the one GPU, gloo between them (host tensors only): each renders its share of the
 views with the HIP path, back-propagates, the losses and gradients are summed over the ranks, one fused
 Adam step follows, and losses, gradients and updated parameters must equal one process doing all the
-views.  Once on a small scene with four views, once on the benchmark's multi-view workload (1M
-Gaussians, 1920x1080, SH degree 3, views 45 degrees apart, one view per rank)."""
+views.  On a small scene with four views and with the benchmark's eight views 45 degrees apart (1 x 8 against
+2 x 4), and on the benchmark's multi-view workload at full size (1M Gaussians, 1920x1080, SH degree 3, one
+view per rank).  The gradient exchange runs in each of its three forms.
+
+The RCCL process group itself (backend "nccl") is formed by bench.py when it runs under a launcher; the last
+test starts it that way as a child process, with one rank."""
+import json
+import subprocess
 import os
 import socket
 import sys
@@ -20,8 +26,14 @@ ROOT = os.path.dirname(HERE)
 SCENES = {
     # name: (Gaussians, width, height, SH degree, views, degrees between views, cloud seed)
     "small_4_views": (3_000, 160, 96, 2, 4, 40.0, 9),
+    # the benchmark's multi-view shape: 8 views 45 degrees apart (one rank does all 8, two ranks do 4 each)
+    "small_8_views": (3_000, 160, 96, 2, 8, 45.0, 9),
     "c4_1M_1080p": (1_000_000, 1920, 1080, 3, 2, 45.0, 0),
 }
+
+
+# which form of the gradient exchange a scene's ranks use (all give the same sums)
+EXCHANGE_OF = {"small_4_views": "all_reduce", "small_8_views": "scatter_gather", "c4_1M_1080p": "direct"}
 
 
 def _setup_path():
@@ -52,7 +64,7 @@ def _run_views(scene, rank, world):
     loss, mine = multiview_step(cams, lambda cam: render(cam, model, pipe, bg)["render"], photometric_loss, targets,
                                 rank=rank, world=world)
     # multiview_step normalised every view's loss by the GLOBAL view count: the sum over ranks is the gradient
-    scale = all_reduce_gradients(opt.params, average=False)
+    scale = all_reduce_gradients(opt.params, average=False, method=EXCHANGE_OF.get(scene, "all_reduce"))
     torch.cuda.synchronize()
     grads = {k: p.grad.detach().cpu() for k, p in opt.params.items()}
     opt.step(grad_scale=scale)
@@ -115,3 +127,20 @@ def test_two_ranks_on_one_gpu_match_one_rank(scene):
         frac = float((abs(p - ref) > 1e-7 * max(1.0, float(abs(ref).max()))).mean())
         print(scene, "param", k, "share of elements that differ %.2e" % frac, flush=True)
         assert frac < 1e-3, k
+
+
+def test_bench_under_a_launcher_forms_the_rccl_group():
+    """bench.py as torch.distributed.run starts it (RANK / WORLD_SIZE / MASTER_* in the environment), one rank:
+    the process group is RCCL ("nccl"), the warm-up collective and the reduction of the mean loss before the
+    closing barrier run on it, and the line says how many ranks the communicator has."""
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        port = s.getsockname()[1]
+    env = dict(os.environ, RANK="0", LOCAL_RANK="0", WORLD_SIZE="1", MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    out = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "1", "--steps", "3", "--warmup", "1",
+                          "--no-cpu-baseline", "--no-variants", "--workload", "c2"], env=env, capture_output=True,
+                         text=True, timeout=600)
+    assert out.returncode == 0, out.stderr[-2000:]
+    line = json.loads(out.stdout.strip().splitlines()[-1])
+    assert line["n_gpus"] == 1 and line["communicator"] == {"backend": "nccl", "ranks": 1}
+    assert line["value"] > 0 and line["ms_per_step"] > 0 and line["mean_loss_over_ranks"] > 0

@@ -108,11 +108,23 @@ def _arena_worker(rank, world, port, q):
     separate = {k: torch.nn.Parameter(torch.zeros_like(p)) for k, p in params.items()}
     for k, p in separate.items():
         p.grad = params[k].grad.clone()                          # the same gradients as free-standing tensors
-    scale = arena.all_reduce()
-    from gsplat_host.optim import all_reduce_gradients
-    assert all_reduce_gradients(separate) == scale
-    for k in params:
-        assert torch.equal(separate[k].grad, params[k].grad)     # per-tensor collectives give the same sums
+    from gsplat_host.optim import EXCHANGES, all_reduce_gradients
+    before = arena.flat.clone()
+    assert arena.flat.numel() % 1024 == 0                        # splits evenly over 2, 4, 8 ... ranks
+    sums = {}
+    for method in EXCHANGES:                                     # reduce-scatter + all-gather, its point-to-point form, one all-reduce
+        arena.flat.copy_(before)
+        scale = arena.all_reduce(method=method)
+        sums[method] = arena.flat.clone()
+    for method in EXCHANGES:
+        assert torch.equal(sums[method], sums["all_reduce"]), method   # two addends: the same bits whatever the route
+    assert float(sums["all_reduce"].abs().sum()) > 0
+    for method in EXCHANGES:                                     # and on free-standing gradient tensors
+        for k, p in separate.items():
+            p.grad = before[arena.offsets[k]:arena.offsets[k] + p.numel()].view_as(p).clone()
+        assert all_reduce_gradients(separate, method=method) == scale
+        for k in params:
+            assert torch.equal(separate[k].grad, params[k].grad), (method, k)
     q.put((rank, scale, {k: (p.grad * scale).clone() for k, p in params.items()}))
     # losses already normalised over all ranks' views: the sum is the gradient, nothing left to scale
     assert all_reduce_gradients({}, average=False) == 1.0 and all_reduce_gradients({}) == 0.5
