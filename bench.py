@@ -311,6 +311,7 @@ def main():
                 events_in_timed_steps=args.events_in_timed_steps)
 
     elapsed, render_ms = m["elapsed"], m["render_ms"]
+    peak_mb = torch.cuda.max_memory_allocated(dev) / 2 ** 20
     if use_dist:
         t = torch.tensor([elapsed, render_ms], device=dev, dtype=torch.float64)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
@@ -402,6 +403,7 @@ def main():
             "gradient_exchange": "all-reduce of all gradients inside the timed step" if args.dp_grads
                                  else "none (the mean loss, one scalar, once per timed region)",
             "communicator": {"backend": dist.get_backend(), "ranks": dist.get_world_size()} if use_dist else None,
+            "peak_device_memory_MB": round(peak_mb, 1),
             "mean_loss_over_ranks": m["mean_loss"],
         }
         if world == 1 and args.workload == "c3" and not args.no_variants and not args.unfused:

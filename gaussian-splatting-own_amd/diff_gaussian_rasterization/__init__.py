@@ -403,9 +403,9 @@ def _gradient_shapes(P: int, raw: bool, n_rest: int = 0, M: int = 0, colors: boo
 
 
 class _GradBlock:
-    """Gradient tensors carved from the forward's allocation: `views` (name -> tensor, shapes as in `shapes`) lie in
-    the `nbytes` bytes at address `at`, which the blend backward clears (`cleared`) before the per-Gaussian backward
-    may take them as zeroed.  `touched` (P bytes, cleared by the forward): the blend backward marks the Gaussians
+    """Gradient tensors carved from one allocation made in the forward: `views` (name -> tensor, shapes as in `shapes`)
+    lie in the `nbytes` bytes at address `at`, which the blend backward clears (`cleared`) before the per-Gaussian
+    backward may take them as zeroed.  `touched` (P bytes, cleared by the forward): the blend backward marks the Gaussians
     it may have sums for, the per-Gaussian backward reads the rows of those only."""
     __slots__ = ("shapes", "views", "touched", "at", "nbytes", "cleared")
 
@@ -418,12 +418,14 @@ _carve_plans: dict = {}
 
 
 def _carve_zero_block(P: int, shapes: dict, dev):
-    """One allocation for everything the backward wants zeroed before it starts: the (P,16) accumulator of the
-    blend backward, the flags of the Gaussians it touches, and the gradient tensors of the per-Gaussian backward
-    (which then writes only the rows of Gaussians that have gradients).  Returns (block, accumulator, flags,
-    {name: tensor}); the pieces start on
-    256-byte boundaries.  One as_strided per piece, from a plan kept per (P, shapes): this runs every step,
-    and at a hundred thousand Gaussians the step is short enough for a dozen extra tensor operations to show."""
+    """Everything the backward wants zeroed before it starts, as TWO allocations: the (P,16) accumulator of the
+    blend backward with the flags of the Gaussians it touches, and the gradient tensors of the per-Gaussian
+    backward (which then writes only the rows of Gaussians that have gradients).  Two, because autograd installs the
+    gradient views as ``param.grad``: in one block with them the accumulator (64 bytes per Gaussian) would stay
+    allocated through the optimiser step.  Returns (accumulator block, accumulator, flags, gradient block,
+    {name: tensor}); the pieces start on 256-byte boundaries.  One as_strided per piece, from a plan kept per
+    (P, shapes): this runs every step, and at a hundred thousand Gaussians the step is short enough for a dozen
+    extra tensor operations to show."""
     key = (P, tuple(shapes.items()))
     plan = _carve_plans.get(key)
     if plan is None:
@@ -437,36 +439,35 @@ def _carve_zero_block(P: int, shapes: dict, dev):
                 run *= d
             return tuple(reversed(out))
         flags_at = pad(P * GRAD_WORDS)          # P bytes of "touched" flags behind the accumulator
-        at = flags_at + pad((P + 3) // 4)
-        pieces = []
+        first_total = flags_at + pad((P + 3) // 4)
+        at, pieces = 0, []
         for k, v in shapes.items():
             pieces.append((k, tuple(v), strides(v), at))
             at += pad(int(torch.Size(v).numel()))
         if len(_carve_plans) > 64:
             _carve_plans.clear()
-        plan = _carve_plans[key] = (at, pieces, flags_at)
-    total, pieces, flags_at = plan
-    block = torch.empty((total,), dtype=torch.float32, device=dev)
-    views = {k: torch.as_strided(block, shape, stride, off) for k, shape, stride, off in pieces}
-    touched = block[flags_at:flags_at + (P + 3) // 4].view(torch.uint8)
-    return block, torch.as_strided(block, (P, GRAD_WORDS), (GRAD_WORDS, 1), 0), touched, views
+        plan = _carve_plans[key] = (first_total, at, pieces, flags_at)
+    first_total, second_total, pieces, flags_at = plan
+    first = torch.empty((first_total,), dtype=torch.float32, device=dev)
+    second = torch.empty((max(second_total, 1),), dtype=torch.float32, device=dev)
+    views = {k: torch.as_strided(second, shape, stride, off) for k, shape, stride, off in pieces}
+    touched = first[flags_at:flags_at + (P + 3) // 4].view(torch.uint8)
+    return first, torch.as_strided(first, (P, GRAD_WORDS), (GRAD_WORDS, 1), 0), touched, second, views
 
 
 def _backward_block(st: ForwardState, raw, shs, cov3D_precomp, dev):
-    """One allocation for the accumulator of the blend backward (st.dsplat) and the flags of the Gaussians it touches, which
-    the forward clears, and the gradient tensors of the per-Gaussian backward (st.zeroed_grads), which the blend backward clears; the
-    per-Gaussian backward then writes only the rows of Gaussians that have gradients.  Returns the accumulator's
-    (address, bytes)."""
+    """The accumulator of the blend backward (st.dsplat) with the flags of the Gaussians it touches, which the
+    forward clears, and the gradient tensors of the per-Gaussian backward (st.zeroed_grads), which the blend backward
+    clears; the per-Gaussian backward then writes only the rows of Gaussians that have gradients.  Returns the
+    accumulator block's (address, bytes)."""
     if raw is not None:
         rest = raw["features_rest"]
         shapes = _gradient_shapes(st.P, True, n_rest=0 if rest is None else rest.shape[1])
     else:
         shapes = _gradient_shapes(st.P, False, M=st.M, colors=shs is None, cov3D=cov3D_precomp is not None)
-    block, st.dsplat, touched, views = _carve_zero_block(st.P, shapes, dev)
-    at = block.data_ptr()
-    nbytes = next(iter(views.values())).data_ptr() - at          # the accumulator and the flags
-    st.zeroed_grads = _GradBlock(shapes, views, touched, at + nbytes, block.numel() * 4 - nbytes)
-    return at, nbytes
+    first, st.dsplat, touched, second, views = _carve_zero_block(st.P, shapes, dev)
+    st.zeroed_grads = _GradBlock(shapes, views, touched, second.data_ptr(), second.numel() * 4)
+    return first.data_ptr(), first.numel() * 4
 
 
 def _thread_callbacks():

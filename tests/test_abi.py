@@ -111,33 +111,40 @@ def test_scratch_and_size_checks_come_before_any_launch():
 
 
 def test_the_backward_block_is_laid_out_as_the_library_expects():
-    """Host logic of the binding, no GPU: the one allocation a prepared forward makes for its backward holds the
-    (P,16) accumulator first, the P `touched` bytes behind it, then every gradient tensor, all on 256-byte
-    boundaries and none overlapping; what the forward clears is the accumulator and the flags, the rest is
-    what the blend backward clears."""
+    """Host logic of the binding, no GPU: a prepared forward makes two allocations for its backward.  The first holds
+    the (P,16) accumulator and, behind it, the P `touched` bytes: what the forward clears.  The second holds every
+    gradient tensor: what the blend backward clears, and all that stays alive once autograd has installed the
+    gradients (the accumulator's 64 bytes per Gaussian are not pinned by them).  Every piece starts on a 256-byte
+    boundary and none overlaps another."""
     import torch
     import diff_gaussian_rasterization as dgr
     for P, shapes in ((1, dgr._gradient_shapes(1, True, n_rest=15)), (1001, dgr._gradient_shapes(1001, True, n_rest=0)),
                       (777, dgr._gradient_shapes(777, False, M=16)), (64, dgr._gradient_shapes(64, False, colors=True, cov3D=True))):
-        block, dsplat, touched, views = dgr._carve_zero_block(P, shapes, torch.device("cpu"))
-        base, end = block.data_ptr(), block.data_ptr() + block.numel() * 4
+        first, dsplat, touched, second, views = dgr._carve_zero_block(P, shapes, torch.device("cpu"))
+        base, end = first.data_ptr(), first.data_ptr() + first.numel() * 4
         assert dsplat.data_ptr() == base and dsplat.shape == (P, 16)
         assert touched.dtype == torch.uint8 and touched.numel() >= P
-        spans = [(dsplat.data_ptr(), dsplat.numel() * 4), (touched.data_ptr(), touched.numel())]
+        assert (touched.data_ptr() - base) % 256 == 0 and dsplat.data_ptr() + dsplat.numel() * 4 <= touched.data_ptr()
+        assert touched.data_ptr() + touched.numel() <= end and (end - base) % 16 == 0
+        gbase, gend = second.data_ptr(), second.data_ptr() + second.numel() * 4
+        assert gend <= base or gbase >= end                          # two allocations
         assert set(views) == set(shapes)
+        spans = []
         for name, v in views.items():
             assert tuple(v.shape) == tuple(shapes[name]) and v.is_contiguous() and v.dtype == torch.float32
+            assert v.untyped_storage().data_ptr() == second.untyped_storage().data_ptr()
             spans.append((v.data_ptr(), v.numel() * 4))
         spans.sort()
         for (a, n), (b, _) in zip(spans, spans[1:]):
-            assert (a - base) % 256 == 0 and a + n <= b
-        assert (spans[-1][0] - base) % 256 == 0 and spans[-1][0] + spans[-1][1] <= end
-        first_grad = min(v.data_ptr() for v in views.values())
-        assert touched.data_ptr() + touched.numel() <= first_grad and (first_grad - base) % 16 == 0
+            assert (a - gbase) % 256 == 0 and a + n <= b
+        assert spans[0][0] == gbase and spans[-1][0] + spans[-1][1] <= gend and (gend - gbase) % 16 == 0
         # writing one piece leaves the others alone
-        block.zero_()
-        views[next(iter(views))].fill_(1.0)
+        first.zero_()
+        second.zero_()
+        name0 = next(iter(views))
+        views[name0].fill_(1.0)
         assert float(dsplat.abs().max()) == 0.0 and int(touched.max()) == 0
+        assert all(float(v.abs().max()) == 0.0 for k, v in views.items() if k != name0)
 
 
 def test_static_sort_scratch_is_as_large_as_the_layout_at_its_capacity():
