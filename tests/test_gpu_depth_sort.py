@@ -57,6 +57,20 @@ def test_one_million_keys_and_the_eight_item_variant():
         _check(_depth_keys(rng, P, 0.3), rng.integers(0, 2**63, P, dtype=np.uint64))
 
 
+def test_exclusive_device_order_gives_the_same_result():
+    """With the caller's word that it has the GPU to itself (this test process does), a sort whose whole grid is
+    resident gives workgroup b chunk b instead of a ticket; the result is the same.  The sizes cover all three
+    keys-per-thread variants, one grid that is resident at once and one (5M keys) that is not and keeps its tickets."""
+    import diff_gaussian_rasterization as dgr
+    rng = np.random.default_rng(11)
+    dgr.assume_exclusive_device(True)
+    try:
+        for P in (4097, 300_001, 1_000_000, 5_000_000):
+            _check(_depth_keys(rng, P, 0.25), rng.integers(0, 2**63, P, dtype=np.uint64))
+    finally:
+        dgr.assume_exclusive_device(False)
+
+
 def test_ties_keep_input_order():
     rng = np.random.default_rng(3)
     P = 200_000
