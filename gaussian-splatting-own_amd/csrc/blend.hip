@@ -12,6 +12,7 @@
 // quadrant cost that wave nothing.
 #include <hip/hip_ext.h>
 
+#include <atomic>
 #include <cstdlib>
 #include <string>
 
@@ -150,6 +151,28 @@ __device__ __forceinline__ void fill_my_share(const ShareFill& f) {
   for (size_t i = first + threadIdx.x; i < end; i += blockDim.x) f.at[i] = make_uint4(0u, 0u, 0u, 0u);
 }
 
+// Depth segments of long tile walks.  A tile's backward walk is serial (every step needs the transmittance
+// and the colour behind it that the step before left), so one tile whose pixels stay translucent ten times
+// deeper than the others' holds the whole kernel up.  The forward therefore writes down every pixel's state
+// each time its walk crosses a multiple of `length` list entries while any pixel of the tile is still
+// open (a "dump": 256 float4, one per pixel of the tile in row-major order: the transmittance in front of
+// the boundary and, once the walk has ended, the colour composited at and behind it), and queues
+// (tile, boundary).  The backward then runs one workgroup per queued boundary k on the entries
+// [(k - 1) length, k length) of that tile, starting from the dump, beside the tile's own workgroup, which only
+// walks the part behind the tile's last dump.  Dumps come from a fixed pool in first-come order; a tile that
+// finds it empty (or has taken kMaxTileDumps) simply stops dumping, and its own workgroup walks the rest.  The
+// forward's host side chooses `length` >= all list entries / pool size, so the pool cannot run dry (a tile takes
+// at most list length / length dumps); below that bound lies only the tests' smaller pool.
+struct Segments {
+  float4* dumps;          // [cap][256]
+  uint2* queue;           // [cap]: tile, boundary (1-based: the boundary in front of entry boundary * length)
+  uint32_t* head;         // [0] dumps asked for (zero before the forward's blend; may end above cap), [1] length, [2] cap
+  uint32_t* tile_dumps;   // [tiles]: boundaries 1 .. tile_dumps[t] of tile t have a dump
+  uint32_t cap, length;   // length: a multiple of 256; 0 = no segments
+};
+constexpr int kMaxTileDumps = 128;
+constexpr uint32_t kSegmentCap = 8192;
+
 inline size_t fill_share(size_t bytes, dim3 grid) {
   const size_t vecs = bytes / 16, groups = (size_t)grid.x * grid.y;
   return (vecs + groups - 1) / groups;
@@ -164,9 +187,10 @@ __global__ void __launch_bounds__(256) blend_fwd_kernel(int W, int H, const uint
                                                         const uint4* __restrict__ records,
                                                         const float* __restrict__ bg, float* __restrict__ out_color,
                                                         float* __restrict__ final_T, uint32_t* __restrict__ n_contrib,
-                                                        ShareFill fill) {
+                                                        ShareFill fill, Segments seg) {
   __shared__ Staged s_splat[kBatch];
   __shared__ unsigned long long s_mask[4][4];  // [quadrant][staging wave]
+  __shared__ uint32_t s_slot[kMaxTileDumps];   // the tile's dumps, in boundary order
 
   const Pixel px = my_pixel(W, H);
   const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
@@ -184,10 +208,31 @@ __global__ void __launch_bounds__(256) blend_fwd_kernel(int W, int H, const uint
   float accept = px.inside ? GSR_ALPHA_MIN : __builtin_inff();
   float T = 1.0f, C0 = 0.f, C1 = 0.f, C2 = 0.f;
   uint32_t last = 0;
+  // depth segments: the batch in front of which the next dump is due, the dumps taken, this pixel's place in one
+  const int seg_rounds = (int)(seg.length / kBatch);
+  int next_dump = seg_rounds ? seg_rounds : 0x7fffffff, dumps = 0;
+  const uint32_t tile = blockIdx.y * gridDim.x + blockIdx.x;
+  const int in_tile = (px.y - (int)blockIdx.y * GSR_TILE_Y) * GSR_TILE_X + (px.x - (int)blockIdx.x * GSR_TILE_X);
 
   for (int b = 0; b < rounds; b++) {
     const bool wave_done = __ballot(accept < __builtin_inff()) == 0ull;
     if (__syncthreads_and(wave_done)) break;   // also fences the previous batch's LDS reads
+    if (b == next_dump) {                      // some pixel is still open at a segment boundary
+      if (threadIdx.x == 0) {
+        const uint32_t slot = atomicAdd(seg.head, 1u);
+        s_slot[dumps] = slot;
+        if (slot < seg.cap) seg.queue[slot] = make_uint2(tile, (uint32_t)dumps + 1u);
+      }
+      __syncthreads();
+      const uint32_t slot = s_slot[dumps];
+      if (slot < seg.cap) {
+        seg.dumps[(size_t)slot * 256 + in_tile] = make_float4(T, C0, C1, C2);
+        dumps++;
+        next_dump = dumps < kMaxTileDumps ? next_dump + seg_rounds : 0x7fffffff;
+      } else {
+        next_dump = 0x7fffffff;                // the pool is empty: the tile's own backward workgroup walks the rest
+      }
+    }
 
     // stage one batch
     const int s = b * kBatch + (int)threadIdx.x;
@@ -245,6 +290,19 @@ __global__ void __launch_bounds__(256) blend_fwd_kernel(int W, int H, const uint
     }
   }
 
+  if (seg.length) {
+    // what the backward wants of a dump is the colour composited at and behind the boundary: the final sums
+    // minus the sums in front of it (each thread rewrites its own words)
+    for (int k = 0; k < dumps; k++) {
+      float4* d = seg.dumps + (size_t)s_slot[k] * 256 + in_tile;
+      const float4 v = *d;
+      *d = make_float4(v.x, C0 - v.y, C1 - v.z, C2 - v.w);
+    }
+    if (threadIdx.x == 0) {
+      seg.tile_dumps[tile] = (uint32_t)dumps;
+      if (tile == 0) { seg.head[1] = seg.length; seg.head[2] = seg.cap; }
+    }
+  }
   if (px.inside) {
     const size_t pix = (size_t)px.y * W + px.x, plane = (size_t)W * H;
     final_T[pix] = T;
@@ -465,6 +523,8 @@ struct StagedPair {
   float2 tail[kPairBatch];   // blue, index bits
 };
 
+// The grid is one-dimensional: first the `extras` workgroups of the queued depth segments (see Segments; the
+// longest items, so they start first), then one workgroup per tile in row-major order.
 __global__ void __launch_bounds__(128) blend_bwd_pair_kernel(int W, int H, const uint2* __restrict__ ranges,
                                                              const uint32_t* __restrict__ point_list,
                                                              const uint4* __restrict__ records,
@@ -473,18 +533,37 @@ __global__ void __launch_bounds__(128) blend_bwd_pair_kernel(int W, int H, const
                                                              const uint32_t* __restrict__ n_contrib,
                                                              const float* __restrict__ dL_dpix,
                                                              float* __restrict__ dL_dsplat,
-                                                             uint8_t* __restrict__ touched, ShareFill fill) {
+                                                             uint8_t* __restrict__ touched, ShareFill fill, Segments seg,
+                                                             int tiles_x, int tiles, int extras) {
   __shared__ __align__(16) StagedPair s_splat;
   __shared__ unsigned long long s_mask[2][2];     // [half tile][staging wave]
   __shared__ int s_last[2];
   __shared__ __align__(16) float s_red[2][8 * kRedStride];
 
+  // this workgroup's item: entries [lo, hi) of one tile's list, from the dump in front of hi if there is one
+  uint32_t tile;
+  int lo = 0, hi = 0x7fffffff;
+  const float4* dump = nullptr;
+  if ((int)blockIdx.x < extras) {
+    const uint32_t queued = min(seg.head[0], min(seg.head[2], seg.cap)), length = seg.head[1];
+    const uint2 q = (uint32_t)blockIdx.x < queued ? seg.queue[blockIdx.x] : make_uint2(0xFFFFFFFFu, 0u);
+    if (q.x >= (uint32_t)tiles || q.y == 0u || q.y > (uint32_t)kMaxTileDumps) { fill_my_share(fill); return; }
+    tile = q.x;
+    hi = (int)(q.y * length);
+    lo = hi - (int)length;
+    dump = seg.dumps + (size_t)blockIdx.x * 256;
+  } else {
+    tile = blockIdx.x - (uint32_t)extras;
+    if (extras) lo = (int)(seg.tile_dumps[tile] * seg.head[1]);
+  }
+  const int tile_x = (int)(tile % (uint32_t)tiles_x), tile_y = (int)(tile / (uint32_t)tiles_x);
+
   const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;     // wave 0: rows 0..7 of the tile, wave 1: rows 8..15
-  const int x0 = blockIdx.x * GSR_TILE_X + (lane & 7), x1 = x0 + 8, y = blockIdx.y * GSR_TILE_Y + wave * 8 + (lane >> 3);
+  const int x0 = tile_x * GSR_TILE_X + (lane & 7), x1 = x0 + 8, y = tile_y * GSR_TILE_Y + wave * 8 + (lane >> 3);
   const bool in0 = x0 < W && y < H, in1 = x1 < W && y < H;
   const float x0f = (float)x0, x1f = (float)x1, yf = (float)y;
-  const float tx0 = (float)(blockIdx.x * GSR_TILE_X), ty0 = (float)(blockIdx.y * GSR_TILE_Y);
-  const uint2 range = ranges[blockIdx.y * gridDim.x + blockIdx.x];
+  const float tx0 = (float)(tile_x * GSR_TILE_X), ty0 = (float)(tile_y * GSR_TILE_Y);
+  const uint2 range = ranges[tile];
   const int total = (int)(range.y - range.x);
 
   const size_t plane = (size_t)W * H, pix0 = (size_t)y * W + x0, pix1 = pix0 + 8;
@@ -500,18 +579,28 @@ __global__ void __launch_bounds__(128) blend_bwd_pair_kernel(int W, int H, const
   for (int o = 32; o > 0; o >>= 1) wl = max(wl, __shfl_xor(wl, o));
   if (lane == 0) s_last[wave] = wl;
   __syncthreads();
-  const int wave_last = __builtin_amdgcn_readfirstlane(wl);
-  const int tile_last = max(s_last[0], s_last[1]);
-  if (tile_last == 0 || total == 0) { fill_my_share(fill); return; }
+  // the deepest position this item visits (exclusive), for the half tile and for the tile
+  const int wave_last = min(__builtin_amdgcn_readfirstlane(wl), hi);
+  const int tile_last = min(max(s_last[0], s_last[1]), hi);
+  if (tile_last <= lo || total == 0) { fill_my_share(fill); return; }
 
+  // A pixel that ended in front of the boundary has its final state in the dump (transmittance = final_T,
+  // nothing behind), one that went on has there what the walk from its own end would have brought here.
   float T0 = Tf0, T1 = Tf1, behind0 = 0.f, behind1 = 0.f;
+  if (dump != nullptr) {
+    const float4 d0 = dump[(wave * 8 + (lane >> 3)) * GSR_TILE_X + (lane & 7)], d1 = dump[(wave * 8 + (lane >> 3)) * GSR_TILE_X + (lane & 7) + 8];
+    T0 = d0.x;
+    T1 = d1.x;
+    behind0 = (d0.y * r0 + d0.z * g0 + d0.w * b0) / d0.x;
+    behind1 = (d1.y * r1 + d1.z * g1 + d1.w * b1) / d1.x;
+  }
   typedef __attribute__((address_space(3))) float lds_float;
   const unsigned red_base = __builtin_amdgcn_readfirstlane((unsigned)(uintptr_t)(lds_float*)s_red[wave]);
   const int my_row = lane >> 3, my_first = (my_row & 2) ? 32 : 0, my_seg = 4 * (lane & 7);
   const float4* const red_lo = reinterpret_cast<const float4*>(s_red[wave] + my_row * kRedStride + my_first + my_seg);
   const float4* const red_hi = reinterpret_cast<const float4*>(s_red[wave] + my_row * kRedStride + (my_first ^ 32) + my_seg);
 
-  for (int b = (tile_last - 1) / kPairBatch; b >= 0; b--) {
+  for (int b = (tile_last - 1) / kPairBatch; b >= lo / kPairBatch; b--) {
     __syncthreads();
     const int s = b * kPairBatch + (int)threadIdx.x;
     unsigned qm = 0u;
@@ -592,88 +681,163 @@ __global__ void __launch_bounds__(128) blend_bwd_pair_kernel(int W, int H, const
 
 namespace {
 
+// Entries per depth segment (0 = none); gsr_debug_segment_length changes it.  2048: deeper than any tile of an
+// ordinary scene is walked (a few hundred entries; 2400 at six million Gaussians with a tenth of the usual
+// opacity), so only walks that would otherwise be the kernel's tail are cut.
+std::atomic<uint32_t> g_segment_length{2048u};
+std::atomic<uint32_t> g_segment_pool{kSegmentCap};     // dumps a forward may take; tests make it small
+
+// The block gsr_forward reserves in its workspace, in the order dumps | queue | tile_dumps | head; the head's
+// 256 bytes come last so that whoever clears memory right behind the block can clear the head with it.
+struct SegmentsLayout {
+  size_t dumps, queue, tile_dumps, head, total;
+};
+
+SegmentsLayout segments_layout(int W, int H) {
+  const size_t tiles = (size_t)gsr::div_up(W, GSR_TILE_X) * gsr::div_up(H, GSR_TILE_Y);
+  SegmentsLayout L;
+  size_t o = 0;
+  auto take = [&](size_t bytes) { const size_t at = o; o += gsr::align_up(bytes, 256); return at; };
+  L.dumps = take((size_t)kSegmentCap * 256 * sizeof(float4));
+  L.queue = take((size_t)kSegmentCap * sizeof(uint2));
+  L.tile_dumps = take(tiles * 4);
+  L.head = take(256);
+  L.total = o;
+  return L;
+}
+
+Segments segments_at(void* block, int W, int H, uint32_t length, uint32_t pool) {
+  if (block == nullptr || length == 0u) return Segments{nullptr, nullptr, nullptr, nullptr, 0u, 0u};
+  const SegmentsLayout L = segments_layout(W, H);
+  char* b = (char*)block;
+  return Segments{(float4*)(b + L.dumps), (uint2*)(b + L.queue), (uint32_t*)(b + L.head), (uint32_t*)(b + L.tile_dumps),
+                  pool < kSegmentCap ? pool : kSegmentCap, length};
+}
+
 // With events the launch goes through hipExtLaunchKernelGGL, which stamps them with the kernel's own
 // start and end (what a profiler's kernel trace reports), instead of with the stream's progress around it.
 int launch_blend_fwd(int W, int H, const uint32_t* ranges, const uint32_t* point_list, const uint32_t* records,
                      const float* bg, float* out_color, float* final_T, uint32_t* n_contrib, void* zero_fill,
-                     size_t zero_fill_bytes, hipEvent_t start, hipEvent_t stop, void* stream) {
+                     size_t zero_fill_bytes, void* segments, uint32_t segment_length, hipEvent_t start, hipEvent_t stop,
+                     void* stream) {
   GSR_REQUIRE(W > 0 && H > 0, "blend_fwd: bad image size %dx%d", W, H);
   GSR_REQUIRE(zero_fill_bytes == 0 || (zero_fill && ((uintptr_t)zero_fill & 15) == 0 && zero_fill_bytes % 16 == 0),
               "blend_fwd: zero_fill must be 16-byte aligned and a multiple of 16 bytes");
   GSR_REQUIRE(ranges && bg && out_color && final_T && n_contrib, "blend_fwd: null pointer");
+  GSR_REQUIRE(((uintptr_t)segments & 255) == 0 && (segments == nullptr || (segment_length != 0u && segment_length % 256u == 0u)),
+              "blend_fwd: the segments block must be 256-byte aligned, the segment length a multiple of 256");
   dim3 grid(gsr::div_up(W, GSR_TILE_X), gsr::div_up(H, GSR_TILE_Y)), block(256);
   GSR_REQUIRE(fill_share(zero_fill_bytes, grid) <= 0xFFFFFFFFull, "blend: zero_fill of %zu bytes is too large for %u workgroups",
               zero_fill_bytes, grid.x * grid.y);
   const ShareFill fill = share_fill(zero_fill, zero_fill_bytes, grid);
+  const Segments seg = segments_at(segments, W, H, segment_length, g_segment_pool.load(std::memory_order_relaxed));
   if (start || stop)
     hipExtLaunchKernelGGL(blend_fwd_kernel, grid, block, 0, (hipStream_t)stream, start, stop, 0, W, H, (const uint2*)ranges,
-                          point_list, (const uint4*)records, bg, out_color, final_T, n_contrib, fill);
+                          point_list, (const uint4*)records, bg, out_color, final_T, n_contrib, fill, seg);
   else
     hipLaunchKernelGGL(blend_fwd_kernel, grid, block, 0, (hipStream_t)stream, W, H, (const uint2*)ranges, point_list,
-                       (const uint4*)records, bg, out_color, final_T, n_contrib, fill);
+                       (const uint4*)records, bg, out_color, final_T, n_contrib, fill, seg);
   return gsr::check_launch("blend_fwd");
 }
 
 int launch_blend_bwd(int W, int H, const uint32_t* ranges, const uint32_t* point_list, const uint32_t* records,
                      const float* bg, const float* final_T, const uint32_t* n_contrib, const float* dL_dpix,
-                     float* dL_dsplat, uint8_t* touched, void* zero_fill, size_t zero_fill_bytes, hipEvent_t start,
-                     hipEvent_t stop, void* stream) {
+                     float* dL_dsplat, uint8_t* touched, void* zero_fill, size_t zero_fill_bytes, const void* segments,
+                     hipEvent_t start, hipEvent_t stop, void* stream) {
   GSR_REQUIRE(W > 0 && H > 0, "blend_bwd: bad image size %dx%d", W, H);
   GSR_REQUIRE(zero_fill_bytes == 0 || (zero_fill && ((uintptr_t)zero_fill & 15) == 0 && zero_fill_bytes % 16 == 0),
               "blend_bwd: zero_fill must be 16-byte aligned and a multiple of 16 bytes");
   GSR_REQUIRE(ranges && bg && final_T && n_contrib && dL_dpix && dL_dsplat, "blend_bwd: null pointer");
   GSR_REQUIRE(((uintptr_t)dL_dsplat & 63) == 0, "blend_bwd: dL_dsplat must be 64-byte aligned");
-  dim3 grid(gsr::div_up(W, GSR_TILE_X), gsr::div_up(H, GSR_TILE_Y)), block(256);
-  GSR_REQUIRE(fill_share(zero_fill_bytes, grid) <= 0xFFFFFFFFull, "blend: zero_fill of %zu bytes is too large for %u workgroups",
-              zero_fill_bytes, grid.x * grid.y);
-  const ShareFill fill = share_fill(zero_fill, zero_fill_bytes, grid);
-  typedef void (*Kernel)(int, int, const uint2*, const uint32_t*, const uint4*, const float*, const float*, const uint32_t*,
-                         const float*, float*, uint8_t*, ShareFill);
-  // GSR_BLEND_BWD=lanes: the one-pixel-per-lane formulation (four waves per tile), for measurements of one
-  // against the other and as an independent implementation in the tests
+  GSR_REQUIRE(((uintptr_t)segments & 255) == 0, "blend_bwd: the segments block must be 256-byte aligned");
+  const dim3 tiles2d(gsr::div_up(W, GSR_TILE_X), gsr::div_up(H, GSR_TILE_Y));
+  // GSR_BLEND_BWD=lanes: the one-pixel-per-lane formulation (four waves per tile, whole walks only), for
+  // measurements of one against the other and as an independent implementation in the tests
   static const bool lanes = [] {
     const char* e = getenv("GSR_BLEND_BWD");
     return e && std::string(e) == "lanes";
   }();
-  const Kernel kernel = lanes ? (Kernel)blend_bwd_kernel : (Kernel)blend_bwd_pair_kernel;
-  if (kernel == (Kernel)blend_bwd_pair_kernel) block = dim3(128);
+  if (lanes) {
+    GSR_REQUIRE(fill_share(zero_fill_bytes, tiles2d) <= 0xFFFFFFFFull, "blend: zero_fill of %zu bytes is too large for %u workgroups",
+                zero_fill_bytes, tiles2d.x * tiles2d.y);
+    const ShareFill fill = share_fill(zero_fill, zero_fill_bytes, tiles2d);
+    if (start || stop)
+      hipExtLaunchKernelGGL(blend_bwd_kernel, tiles2d, dim3(256), 0, (hipStream_t)stream, start, stop, 0, W, H, (const uint2*)ranges,
+                            point_list, (const uint4*)records, bg, final_T, n_contrib, dL_dpix, dL_dsplat, touched, fill);
+    else
+      hipLaunchKernelGGL(blend_bwd_kernel, tiles2d, dim3(256), 0, (hipStream_t)stream, W, H, (const uint2*)ranges, point_list,
+                         (const uint4*)records, bg, final_T, n_contrib, dL_dpix, dL_dsplat, touched, fill);
+    return gsr::check_launch("blend_bwd");
+  }
+  // the segment length the kernel works with is the one the forward left in the block
+  const Segments seg = segments_at(const_cast<void*>(segments), W, H, 256u, kSegmentCap);
+  const int tiles = (int)(tiles2d.x * tiles2d.y), extras = segments ? (int)kSegmentCap : 0;
+  const dim3 grid((unsigned)(tiles + extras));
+  GSR_REQUIRE(fill_share(zero_fill_bytes, grid) <= 0xFFFFFFFFull, "blend: zero_fill of %zu bytes is too large for %u workgroups",
+              zero_fill_bytes, grid.x);
+  const ShareFill fill = share_fill(zero_fill, zero_fill_bytes, grid);
   if (start || stop)
-    hipExtLaunchKernelGGL(kernel, grid, block, 0, (hipStream_t)stream, start, stop, 0, W, H, (const uint2*)ranges,
-                          point_list, (const uint4*)records, bg, final_T, n_contrib, dL_dpix, dL_dsplat, touched, fill);
+    hipExtLaunchKernelGGL(blend_bwd_pair_kernel, grid, dim3(128), 0, (hipStream_t)stream, start, stop, 0, W, H,
+                          (const uint2*)ranges, point_list, (const uint4*)records, bg, final_T, n_contrib, dL_dpix, dL_dsplat,
+                          touched, fill, seg, (int)tiles2d.x, tiles, extras);
   else
-    hipLaunchKernelGGL(kernel, grid, block, 0, (hipStream_t)stream, W, H, (const uint2*)ranges, point_list,
-                       (const uint4*)records, bg, final_T, n_contrib, dL_dpix, dL_dsplat, touched, fill);
+    hipLaunchKernelGGL(blend_bwd_pair_kernel, grid, dim3(128), 0, (hipStream_t)stream, W, H, (const uint2*)ranges, point_list,
+                       (const uint4*)records, bg, final_T, n_contrib, dL_dpix, dL_dsplat, touched, fill, seg, (int)tiles2d.x,
+                       tiles, extras);
   return gsr::check_launch("blend_bwd");
 }
 
 }  // namespace
 
+extern "C" void gsr_debug_segments(uint32_t entries, uint32_t pool) {
+  g_segment_length.store((entries + 255u) / 256u * 256u, std::memory_order_relaxed);
+  g_segment_pool.store(pool ? pool : kSegmentCap, std::memory_order_relaxed);
+}
+
+// Entries per segment for lists of N entries in all: the configured length, or as many more as it takes for the
+// pool to hold every boundary (sum over the tiles of floor(list length / length) <= N / length <= kSegmentCap).
+// A longer segment than configured costs nothing there: with N / kSegmentCap entries per segment and a few
+// thousand workgroups resident, the longest item is still a fraction of a workgroup slot's share of the work.
+uint32_t gsr::segment_length_for(uint32_t N) {
+  const uint32_t configured = g_segment_length.load(std::memory_order_relaxed);
+  if (configured == 0u) return 0u;
+  const uint32_t fits = (N / kSegmentCap + 256u) / 256u * 256u;
+  return configured > fits ? configured : fits;
+}
+
+size_t gsr::segments_bytes(int W, int H) { return segments_layout(W, H).total; }
+
+uint32_t* gsr::segments_head(void* block, int W, int H) {
+  return block ? (uint32_t*)((char*)block + segments_layout(W, H).head) : nullptr;
+}
+
 extern "C" int gsr_blend_fwd(int W, int H, const uint32_t* ranges, const uint32_t* point_list,
                              const uint32_t* records, const float* bg, float* out_color, float* final_T,
                              uint32_t* n_contrib, void* stream) {
-  return launch_blend_fwd(W, H, ranges, point_list, records, bg, out_color, final_T, n_contrib, nullptr, 0, nullptr, nullptr,
-                          stream);
+  return launch_blend_fwd(W, H, ranges, point_list, records, bg, out_color, final_T, n_contrib, nullptr, 0, nullptr, 0u, nullptr,
+                          nullptr, stream);
 }
 
 extern "C" int gsr_blend_bwd(int W, int H, const uint32_t* ranges, const uint32_t* point_list,
                              const uint32_t* records, const float* bg, const float* final_T,
                              const uint32_t* n_contrib, const float* dL_dpix, float* dL_dsplat, void* stream) {
   return launch_blend_bwd(W, H, ranges, point_list, records, bg, final_T, n_contrib, dL_dpix, dL_dsplat, nullptr, nullptr, 0,
-                          nullptr, nullptr, stream);
+                          nullptr, nullptr, nullptr, stream);
 }
 
 extern "C" int gsr_blend_fwd_timed(int W, int H, const uint32_t* ranges, const uint32_t* point_list,
                                    const uint32_t* records, const float* bg, float* out_color, float* final_T,
                                    uint32_t* n_contrib, void* start_event, void* stop_event, void* stream) {
-  return launch_blend_fwd(W, H, ranges, point_list, records, bg, out_color, final_T, n_contrib, nullptr, 0,
+  return launch_blend_fwd(W, H, ranges, point_list, records, bg, out_color, final_T, n_contrib, nullptr, 0, nullptr, 0u,
                           (hipEvent_t)start_event, (hipEvent_t)stop_event, stream);
 }
 
 int gsr::blend_fwd(int W, int H, const uint32_t* ranges, const uint32_t* point_list, const uint32_t* records,
                    const float* bg, float* out_color, float* final_T, uint32_t* n_contrib, void* zero_fill,
-                   size_t zero_fill_bytes, void* start_event, void* stop_event, hipStream_t stream) {
+                   size_t zero_fill_bytes, void* segments, uint32_t segment_length, void* start_event, void* stop_event,
+                   hipStream_t stream) {
   return launch_blend_fwd(W, H, ranges, point_list, records, bg, out_color, final_T, n_contrib, zero_fill, zero_fill_bytes,
-                          (hipEvent_t)start_event, (hipEvent_t)stop_event, stream);
+                          segments, segment_length, (hipEvent_t)start_event, (hipEvent_t)stop_event, stream);
 }
 
 extern "C" int gsr_blend_bwd_timed(int W, int H, const uint32_t* ranges, const uint32_t* point_list,
@@ -681,7 +845,7 @@ extern "C" int gsr_blend_bwd_timed(int W, int H, const uint32_t* ranges, const u
                                    const uint32_t* n_contrib, const float* dL_dpix, float* dL_dsplat,
                                    void* start_event, void* stop_event, void* stream) {
   return launch_blend_bwd(W, H, ranges, point_list, records, bg, final_T, n_contrib, dL_dpix, dL_dsplat, nullptr, nullptr, 0,
-                          (hipEvent_t)start_event, (hipEvent_t)stop_event, stream);
+                          nullptr, (hipEvent_t)start_event, (hipEvent_t)stop_event, stream);
 }
 
 extern "C" int gsr_blend_bwd_fill(int W, int H, const uint32_t* ranges, const uint32_t* point_list,
@@ -690,5 +854,14 @@ extern "C" int gsr_blend_bwd_fill(int W, int H, const uint32_t* ranges, const ui
                                   void* zero_fill, size_t zero_fill_bytes, void* start_event, void* stop_event,
                                   void* stream) {
   return launch_blend_bwd(W, H, ranges, point_list, records, bg, final_T, n_contrib, dL_dpix, dL_dsplat, touched, zero_fill,
-                          zero_fill_bytes, (hipEvent_t)start_event, (hipEvent_t)stop_event, stream);
+                          zero_fill_bytes, nullptr, (hipEvent_t)start_event, (hipEvent_t)stop_event, stream);
+}
+
+extern "C" int gsr_blend_bwd_segments(int W, int H, const uint32_t* ranges, const uint32_t* point_list,
+                                      const uint32_t* records, const float* bg, const float* final_T,
+                                      const uint32_t* n_contrib, const float* dL_dpix, float* dL_dsplat,
+                                      uint8_t* touched, void* zero_fill, size_t zero_fill_bytes, const void* segments,
+                                      void* start_event, void* stop_event, void* stream) {
+  return launch_blend_bwd(W, H, ranges, point_list, records, bg, final_T, n_contrib, dL_dpix, dL_dsplat, touched, zero_fill,
+                          zero_fill_bytes, segments, (hipEvent_t)start_event, (hipEvent_t)stop_event, stream);
 }

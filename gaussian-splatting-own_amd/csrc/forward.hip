@@ -25,7 +25,7 @@ struct Carve {
 
 struct Workspace {
   uint32_t* records; uint32_t* depth_keys; uint64_t* sort_vals; uint64_t* sorted_vals; uint32_t* totals;
-  void* sort_scratch; size_t sort_bytes; uint32_t* ranges; float* final_T; uint32_t* n_contrib; size_t total;
+  void* segments; void* sort_scratch; size_t sort_bytes; uint32_t* ranges; float* final_T; uint32_t* n_contrib; size_t total;
 };
 
 Workspace carve(void* base, int P, int W, int H) {
@@ -37,6 +37,9 @@ Workspace carve(void* base, int P, int W, int H) {
   w.sort_vals = c.take<uint64_t>(p * 8);
   w.sorted_vals = c.take<uint64_t>(p * 8);
   w.totals = c.take<uint32_t>(gsr_totals_words(P) * 4);
+  // the segments block ends with the words the blend wants zeroed, the sort's scratch begins with the words the
+  // sort wants zeroed: side by side they are one region for the preprocess to clear
+  w.segments = c.take<char>(gsr::segments_bytes(W, H));
   w.sort_bytes = gsr_bin_sort_bytes(P);
   w.sort_scratch = c.take<char>(w.sort_bytes);
   w.ranges = c.take<uint32_t>(tiles * 8);
@@ -109,6 +112,10 @@ extern "C" int gsr_forward(const GsrForwardArgs* a, gsr_resize_fn resize, void* 
 
   uint32_t N = 0, E1 = 0, E2 = 0, V = 0;
   const uint32_t* sort_error = nullptr;
+  // depth segments for the backward (the preprocess clears their counter: none without Gaussians)
+  static const bool no_segments = getenv("GSR_NO_SEGMENTS") != nullptr;   // for measurements of the difference
+  void* const segments = (P > 0 && !no_segments && gsr::segment_length_for(0u) != 0u) ? w.segments : nullptr;
+  out->segments = segments;
   GSR_REQUIRE(a->zero_fill_bytes == 0 || (a->zero_fill && ((uintptr_t)a->zero_fill & 15) == 0 && a->zero_fill_bytes % 16 == 0),
               "forward: the zero-fill must be 16-byte aligned and a multiple of 16 bytes");
   if (P > 0) {
@@ -128,6 +135,12 @@ extern "C" int gsr_forward(const GsrForwardArgs* a, gsr_resize_fn resize, void* 
     static const bool sort_clears = getenv("GSR_SORT_CLEARS_ITSELF") != nullptr;   // for measurements of the difference
     gsr::PreprocessExtras extras{landing != nullptr, nullptr, 0};
     if (!sort_clears) gsr::depth_sort_clear_region(P, w.sort_scratch, &extras.clear_at, &extras.clear_words);
+    if (segments) {
+      uint32_t* head = gsr::segments_head(segments, W, H);
+      const size_t head_words = (size_t)((uint32_t*)w.sort_scratch - head);
+      if (extras.clear_words) extras.clear_words += head_words; else extras.clear_words = head_words;
+      extras.clear_at = head;
+    }
     if (a->raw)
       rc = gsr::preprocess_fwd_raw(extras, P, a->D, a->M - 1, a->means3D, a->scales, a->scale_modifier, a->rotations, a->opacities,
                                   a->shs, a->shs_rest, a->viewmatrix, a->projmatrix, a->campos, W, H, a->tanfovx,
@@ -189,7 +202,7 @@ extern "C" int gsr_forward(const GsrForwardArgs* a, gsr_resize_fn resize, void* 
   if (a->before_blend) a->before_blend(a->hook_ctx);
   // the caller's zero-fill rides on the blend kernel, whose workgroups leave HBM almost idle
   rc = gsr::blend_fwd(W, H, w.ranges, out->point_list, w.records, a->bg, a->out_color, w.final_T, w.n_contrib, a->zero_fill,
-                      a->zero_fill_bytes, a->blend_start_event, a->blend_stop_event, st);
+                      a->zero_fill_bytes, segments, gsr::segment_length_for(N), a->blend_start_event, a->blend_stop_event, st);
   if (rc) return rc;
   return checkpoint("blend");
 }

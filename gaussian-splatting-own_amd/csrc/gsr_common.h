@@ -161,10 +161,16 @@ void set_sort_spin_limit(uint32_t limit);
 // The caller has the GPU to itself: sorts may skip the per-workgroup ticket (see depthsort.hip).
 void set_exclusive_device(int on);
 
-// gsr_blend_fwd_timed with a zero-fill: every workgroup clears an equal share of it as its last act.
+// gsr_blend_fwd_timed with a zero-fill: every workgroup clears an equal share of it as its last act; and with
+// the block for the depth segments of long walks (null = none; see blend.hip): segments_bytes(W, H) bytes,
+// 256-byte aligned, whose last 256 bytes (from segments_head) must be zero when the kernel starts; segment_length
+// (a multiple of 256, from segment_length_for) entries per segment.
 int blend_fwd(int W, int H, const uint32_t* ranges, const uint32_t* point_list, const uint32_t* records, const float* bg,
               float* out_color, float* final_T, uint32_t* n_contrib, void* zero_fill, size_t zero_fill_bytes,
-              void* start_event, void* stop_event, hipStream_t stream);
+              void* segments, uint32_t segment_length, void* start_event, void* stop_event, hipStream_t stream);
+size_t segments_bytes(int W, int H);
+uint32_t* segments_head(void* block, int W, int H);
+uint32_t segment_length_for(uint32_t N);   // entries per depth segment for lists of N entries, 0 = no segments
 
 }  // namespace gsr
 

@@ -78,7 +78,7 @@ class _ForwardOut(C.Structure):
                 ("carried_status", C.c_uint32),
                 ("records", C.c_void_p), ("depth_keys", C.c_void_p), ("sorted_vals", C.c_void_p),
                 ("ranges", C.c_void_p), ("final_T", C.c_void_p), ("n_contrib", C.c_void_p),
-                ("point_list", C.c_void_p), ("tile_ids_sorted", C.c_void_p)]
+                ("point_list", C.c_void_p), ("tile_ids_sorted", C.c_void_p), ("segments", C.c_void_p)]
 
 
 _RESIZE_FN = C.CFUNCTYPE(C.c_void_p, C.c_void_p, C.c_size_t)
@@ -118,6 +118,8 @@ def _load():
     lib.gsr_blend_fwd_timed.argtypes = [ci, ci, vp, vp, vp, vp, vp, vp, vp, vp, vp, vp]
     lib.gsr_blend_bwd_timed.argtypes = [ci, ci, vp, vp, vp, vp, vp, vp, vp, vp, vp, vp, vp]
     lib.gsr_blend_bwd_fill.argtypes = [ci, ci, vp, vp, vp, vp, vp, vp, vp, vp, vp, vp, C.c_size_t, vp, vp, vp]
+    lib.gsr_blend_bwd_segments.argtypes = [ci, ci, vp, vp, vp, vp, vp, vp, vp, vp, vp, vp, C.c_size_t, vp, vp, vp, vp]
+    lib.gsr_debug_segments.argtypes, lib.gsr_debug_segments.restype = [u32, u32], None
     lib.gsr_event_create.restype = vp
     lib.gsr_event_create_untimed.restype = vp
     lib.gsr_event_destroy.argtypes, lib.gsr_event_destroy.restype = [vp], None
@@ -142,6 +144,33 @@ def assume_exclusive_device(on: bool = True) -> None:
     kernels of its own): the depth sort may then skip its per-workgroup tickets when its whole grid is resident
     at once.  Off by default; GSR_EXCLUSIVE_DEVICE=1 in the environment sets it too."""
     _lib.gsr_assume_exclusive_device(int(bool(on)))
+
+
+def set_segment_length(entries: int, pool: int = 0) -> None:
+    """Entries per depth segment of the blend backward from now on, and the number of boundary records a forward
+    may take (gsr_debug_segments in gsr.h): the library's own 2048 and 8192 suit real scenes; tests of the path on
+    small scenes set them lower, 0 entries switches the segments off, pool 0 is the whole pool."""
+    _lib.gsr_debug_segments(int(entries), int(pool))
+
+
+SEGMENT_POOL = 8192        # dumps in a forward's pool (kSegmentCap in blend.hip)
+
+
+def segment_counts(st) -> tuple:
+    """(dumps the forward's blend asked for, entries per segment it worked with, dumps per tile) of a single-call
+    forward that kept depth segments, read from the block gsr_forward returned; waits for the device.  The block's
+    layout is blend.hip's SegmentsLayout: pool of SEGMENT_POOL dumps of 4096 bytes | queue of 8 bytes each |
+    one word per tile | 256 bytes that start with the two counters, every piece padded to 256 bytes."""
+    if st.segments is None:
+        return 0, 0, None
+    tiles = ((st.W + TILE - 1) // TILE) * ((st.H + TILE - 1) // TILE)
+    pad = lambda n: (n + 255) // 256 * 256
+    storage = st.records.untyped_storage()
+    at = st.segments - storage.data_ptr() + SEGMENT_POOL * 4096 + pad(SEGMENT_POOL * 8)
+    words = torch.empty(0, dtype=torch.int32, device=st.records.device).set_(storage, at // 4, (pad(tiles * 4) // 4 + 3,))
+    host = words.cpu()
+    head = pad(tiles * 4) // 4
+    return int(host[head]) & 0xFFFFFFFF, int(host[head + 1]), host[:tiles].clone()
 
 
 class StageTimer:
@@ -334,7 +363,7 @@ class ForwardState:
     and the intermediate buffers the parity tests inspect."""
     __slots__ = ("P", "M", "D", "W", "H", "records", "radii", "depth_keys", "sorted_vals",
                  "num_rendered", "num_visible", "dsplat", "zeroed_grads", "visible", "point_list", "ranges", "tile_ids_sorted", "color", "final_T", "n_contrib",
-                 "view", "proj", "campos", "bg")
+                 "view", "proj", "campos", "bg", "segments")
 
     # views into the 64-byte records, named as the oracle names them
     @property
@@ -589,6 +618,7 @@ def _forward_single_call(s, st, dev, means3D, opacities, shs, colors_precomp, sc
     st.point_list = view(lists, lists.data_ptr(), out.point_list, N, torch.int32, (N,))
     st.tile_ids_sorted = (view(lists, lists.data_ptr(), out.tile_ids_sorted, N, torch.int32, (N,))
                           if keep_tile_ids else None)
+    st.segments = out.segments            # inside ws, which the views above keep alive
 
 
 def rasterize_forward(s: GaussianRasterizationSettings, means3D, opacities, shs=None, colors_precomp=None,
@@ -617,6 +647,7 @@ def rasterize_forward(s: GaussianRasterizationSettings, means3D, opacities, shs=
     st.campos, st.bg = _f32(s.campos, "campos"), _f32(s.bg, "bg")
     st.dsplat = None
     st.zeroed_grads = None
+    st.segments = None
     ref_lists = int(REFERENCE_LISTS if reference_lists is None else reference_lists)
     # a timer that brackets stages with events needs the stage calls; one that only wants the blend kernels' own
     # events does not
@@ -732,8 +763,8 @@ def blend_backward(st: ForwardState, grad_color: torch.Tensor) -> torch.Tensor:
         held = st.zeroed_grads
         fill = (None, None, 0) if held is None or held.cleared else (_ptr(held.touched), C.c_void_p(held.at), held.nbytes)
         args = (st.W, st.H, _ptr(st.ranges), _ptr(st.point_list), _ptr(st.records), _ptr(st.bg), _ptr(st.final_T),
-                _ptr(st.n_contrib), _ptr(grad_color), _ptr(dsplat), *fill)
-        _run_blend("blend_bwd", lambda *a: _lib.gsr_blend_bwd_fill(*a[:-1], None, None, a[-1]), _lib.gsr_blend_bwd_fill, *args)
+                _ptr(st.n_contrib), _ptr(grad_color), _ptr(dsplat), *fill, C.c_void_p(st.segments))
+        _run_blend("blend_bwd", lambda *a: _lib.gsr_blend_bwd_segments(*a[:-1], None, None, a[-1]), _lib.gsr_blend_bwd_segments, *args)
         if held is not None:
             held.cleared = True
     return dsplat

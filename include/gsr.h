@@ -46,7 +46,7 @@
 extern "C" {
 #endif
 
-#define GSR_VERSION 5
+#define GSR_VERSION 6
 
 #define GSR_OK 0
 #define GSR_E_INVALID (-1)   /* bad argument (null pointer, negative size, unsupported M/D) */
@@ -313,6 +313,7 @@ typedef struct GsrForwardOut {
   uint32_t N, V, E1, E2, carried_status;
   uint32_t* records; uint32_t* depth_keys; uint64_t* sorted_vals; uint32_t* ranges; float* final_T;
   uint32_t* n_contrib; uint32_t* point_list; uint32_t* tile_ids_sorted;
+  void* segments;   /* inside the workspace; for gsr_blend_bwd_segments (NULL: none were kept) */
 } GsrForwardOut;
 size_t gsr_forward_workspace_bytes(int P, int W, int H);
 int gsr_forward(const GsrForwardArgs* args, gsr_resize_fn resize, void* resize_ctx, GsrForwardOut* out,
@@ -351,6 +352,30 @@ int gsr_blend_bwd_fill(int W, int H, const uint32_t* ranges, const uint32_t* poi
                        const uint32_t* n_contrib, const float* dL_dpix, float* dL_dsplat,
                        uint8_t* touched, void* zero_fill, size_t zero_fill_bytes, void* start_event,
                        void* stop_event, void* stream);
+
+/* gsr_blend_bwd_fill for the lists of a gsr_forward call, with the depth segments that call kept
+ * (GsrForwardOut.segments; NULL = gsr_blend_bwd_fill).  A tile's backward walk is serial, so a single
+ * tile whose pixels stay translucent many times deeper than the others' (a dense cluster right after the
+ * reference's reset_opacity, scene/gaussian_model.py:210-213, when every opacity is at most 0.01) holds the
+ * whole kernel up.  gsr_forward's blend therefore writes down every pixel's transmittance and composited
+ * colour each time a tile's walk crosses a multiple of L list entries with a pixel still open (L = 2048, or
+ * N / 8192 rounded up to a multiple of 256 if that is more), into a pool of 8192 such records inside the
+ * workspace (32 MB, enough for every boundary there can be), and this call walks each of those stretches of
+ * L entries in a workgroup of its own, beside the workgroup of the tile.  Same sums as gsr_blend_bwd up to rounding (the atomic additions arrive in another order; the
+ * state at a boundary is the forward's, not the one unwound from the pixel's end).  Scenes whose tiles are
+ * walked less than 2048 entries deep (every ordinary one) cost the forward nothing and this call a
+ * microsecond.  The reference has no counterpart: its backward (diff-gaussian-rasterization,
+ * RasterizeGaussiansBackwardCUDA) walks every tile in one block.
+ * gsr_debug_segments: from now on, for this process, `entries` instead of 2048 (rounded up to a multiple of
+ * 256; 0 = gsr_forward keeps no segments) and a pool of `pool` records (0 = all 8192; with fewer a forward
+ * can find the pool empty, and the tiles that come too late are walked whole), for tests of the path on small
+ * scenes. */
+int gsr_blend_bwd_segments(int W, int H, const uint32_t* ranges, const uint32_t* point_list,
+                           const uint32_t* records, const float* bg, const float* final_T,
+                           const uint32_t* n_contrib, const float* dL_dpix, float* dL_dsplat,
+                           uint8_t* touched, void* zero_fill, size_t zero_fill_bytes, const void* segments,
+                           void* start_event, void* stop_event, void* stream);
+void gsr_debug_segments(uint32_t entries, uint32_t pool);
 
 /* ---- Kernel-exact timing of the two blend kernels ----------------------------
  * The same calls with a pair of events (hipEvent_t passed as void*, from

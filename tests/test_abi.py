@@ -35,7 +35,7 @@ def test_library_exports_every_declared_symbol():
     for s in declared_symbols():
         assert hasattr(lib, s), s
     lib.gsr_version.restype = ctypes.c_int
-    assert lib.gsr_version() == 5
+    assert lib.gsr_version() == 6
     lib.gsr_last_error.restype = ctypes.c_char_p
     assert isinstance(lib.gsr_last_error(), bytes)
 

@@ -38,6 +38,8 @@ for op in [float(a) for a in sys.argv[1:]] or [0.1]:
         dgr.set_stage_timer(None)
         ex = timer.exact_ms()
         timer.close()
-    print(f"opacity {op}: lists {lists}  " + "  ".join(f"{k} {v[0] * 1e3:.0f} us" for k, v in sorted(ex.items())), flush=True)
+    asked, length, per_tile = dgr.segment_counts(st)
+    cut = f"depth segments of {length}: {asked} dumps, {int(per_tile.max())} in one tile  " if length else "whole walks  "
+    print(f"opacity {op}: lists {lists}  " + cut + "  ".join(f"{k} {v[0] * 1e3:.0f} us" for k, v in sorted(ex.items())), flush=True)
     del scene, st, model
     torch.cuda.empty_cache()
