@@ -37,7 +37,8 @@ through the reference's unchanged operator API (`reference_operator_api`:
 PyTorch activations feeding GaussianRasterizer, what a user of the drop-in gets
 without changing a line), and as `variants` the no-early-termination scene
 (every opacity 0.1, the reference's initial value, scene/gaussian_model.py:139)
-and the skewed 6M cloud with the same opacities (c5w).
+and the skewed 6M cloud with the same opacities (c5w) and with every opacity
+0.01 (c5r: the state after the reference's reset_opacity).
 """
 from __future__ import annotations
 
@@ -70,6 +71,9 @@ WORKLOADS = {
     "c5": (6_000_000, 1920, 1080, 3, 0.5, None),
     # the worst case for tile-load skew: the C5 cloud (half of the Gaussians in a hot spot) with every opacity 0.1
     "c5w": (6_000_000, 1920, 1080, 3, 0.5, 0.1),
+    # the same cloud as the reference's reset_opacity leaves it (scene/gaussian_model.py:210-213: every opacity at most
+    # 0.01): the hot spot's tiles are walked tens of thousands of entries deep, the case the depth segments are for
+    "c5r": (6_000_000, 1920, 1080, 3, 0.5, 0.01),
 }
 
 SETTLE_STEPS = 40                 # untimed steps a measurement starts with, the W warm-up steps included
@@ -421,7 +425,8 @@ def variants(scene, dgr, args, dev):
     reference's unchanged operator API (its model getters as PyTorch ops feeding GaussianRasterizer,
     gaussian_renderer/__init__.py:53-93), returned first; then, as a dict, on the same cloud with every opacity 0.1
     (the reference's initial opacity: nothing saturates early, the hard case for the blend kernels) and on the
-    skewed 6M cloud with those opacities (the worst case for tile-load skew)."""
+    skewed 6M cloud with those opacities (the worst case for tile-load skew) and with every opacity 0.01 (the worst
+    case for the depth of single tiles' walks)."""
     steps, warmup = max(5, args.steps // 2), 3
     m = measure(scene, dgr, False, steps, warmup, stage_table=False)
     api = {
@@ -433,7 +438,10 @@ def variants(scene, dgr, args, dev):
     for name, key, what in (
             ("c3w", "c3w_opacity_0.1", "the same cloud with every opacity 0.1 (scene/gaussian_model.py:139): no early termination"),
             ("c5w", "c5w_skew_opacity_0.1", "6M Gaussians, half of them in a hot spot, every opacity 0.1: tile-load skew "
-                                            "without early termination")):
+                                            "without early termination"),
+            ("c5r", "c5r_skew_opacity_0.01", "the same 6M cloud with every opacity 0.01, as after the reference's reset_opacity "
+                                             "(scene/gaussian_model.py:210-213): single tiles are walked many times deeper than "
+                                             "the rest, the backward cuts those walks into depth segments")):
         hard = Scene(name, dev, 0)
         m = measure(hard, dgr, True, steps, warmup, stage_table=True)
         lists = _list_stats(dgr, hard)
@@ -485,6 +493,10 @@ def _list_stats(dgr, scene):
                                          "share_of_walk_in_the_deepest_1pct_of_tiles":
                                              round(float(depth.sort().values[-max(1, depth.numel() // 100):].sum() / depth.sum().clamp_min(1)), 4)},
                "pixel_splat_pairs": {"listed": 256 * int(st.num_rendered), "to_last_contributor": int(nc.sum())}}
+        asked, seg_len, per_tile = dgr.segment_counts(st)
+        if seg_len:
+            out["depth_segments"] = {"entries_per_segment": seg_len, "boundaries_recorded": asked,
+                                     "most_in_one_tile": int(per_tile.max())}
         del st
         return out
 

@@ -144,9 +144,12 @@ struct ShareFill {
   uint32_t share;   // vectors per workgroup: ceil(vecs / workgroups)
 };
 
-__device__ __forceinline__ void fill_my_share(const ShareFill& f) {
+__device__ __forceinline__ void fill_my_share(const ShareFill& f, unsigned group);
+__device__ __forceinline__ void fill_my_share(const ShareFill& f) { fill_my_share(f, blockIdx.y * gridDim.x + blockIdx.x); }
+
+__device__ __forceinline__ void fill_my_share(const ShareFill& f, unsigned group) {
   if (f.vecs == 0) return;
-  const size_t first = ((size_t)blockIdx.y * gridDim.x + blockIdx.x) * f.share;
+  const size_t first = (size_t)group * f.share;
   const size_t end = first + f.share < f.vecs ? first + f.share : f.vecs;
   for (size_t i = first + threadIdx.x; i < end; i += blockDim.x) f.at[i] = make_uint4(0u, 0u, 0u, 0u);
 }
@@ -547,7 +550,7 @@ __global__ void __launch_bounds__(128) blend_bwd_pair_kernel(int W, int H, const
   if ((int)blockIdx.x < extras) {
     const uint32_t queued = min(seg.head[0], min(seg.head[2], seg.cap)), length = seg.head[1];
     const uint2 q = (uint32_t)blockIdx.x < queued ? seg.queue[blockIdx.x] : make_uint2(0xFFFFFFFFu, 0u);
-    if (q.x >= (uint32_t)tiles || q.y == 0u || q.y > (uint32_t)kMaxTileDumps) { fill_my_share(fill); return; }
+    if (q.x >= (uint32_t)tiles || q.y == 0u || q.y > (uint32_t)kMaxTileDumps) return;
     tile = q.x;
     hi = (int)(q.y * length);
     lo = hi - (int)length;
@@ -582,7 +585,10 @@ __global__ void __launch_bounds__(128) blend_bwd_pair_kernel(int W, int H, const
   // the deepest position this item visits (exclusive), for the half tile and for the tile
   const int wave_last = min(__builtin_amdgcn_readfirstlane(wl), hi);
   const int tile_last = min(max(s_last[0], s_last[1]), hi);
-  if (tile_last <= lo || total == 0) { fill_my_share(fill); return; }
+  // the zero-fill is the tiles' workgroups' (a workgroup of the queue that finds no item would clear its share
+  // at once, ahead of everybody's work, where the stores are in the way)
+  const bool fills = (int)blockIdx.x >= extras;
+  if (tile_last <= lo || total == 0) { if (fills) fill_my_share(fill, tile); return; }
 
   // A pixel that ended in front of the boundary has its final state in the dump (transmittance = final_T,
   // nothing behind), one that went on has there what the walk from its own end would have brought here.
@@ -674,7 +680,7 @@ __global__ void __launch_bounds__(128) blend_bwd_pair_kernel(int W, int H, const
       }
     }
   }
-  fill_my_share(fill);
+  if (fills) fill_my_share(fill, tile);
 }
 
 }  // namespace
@@ -773,9 +779,9 @@ int launch_blend_bwd(int W, int H, const uint32_t* ranges, const uint32_t* point
   const Segments seg = segments_at(const_cast<void*>(segments), W, H, 256u, kSegmentCap);
   const int tiles = (int)(tiles2d.x * tiles2d.y), extras = segments ? (int)kSegmentCap : 0;
   const dim3 grid((unsigned)(tiles + extras));
-  GSR_REQUIRE(fill_share(zero_fill_bytes, grid) <= 0xFFFFFFFFull, "blend: zero_fill of %zu bytes is too large for %u workgroups",
-              zero_fill_bytes, grid.x);
-  const ShareFill fill = share_fill(zero_fill, zero_fill_bytes, grid);
+  GSR_REQUIRE(fill_share(zero_fill_bytes, tiles2d) <= 0xFFFFFFFFull, "blend: zero_fill of %zu bytes is too large for %u workgroups",
+              zero_fill_bytes, tiles2d.x * tiles2d.y);
+  const ShareFill fill = share_fill(zero_fill, zero_fill_bytes, tiles2d);
   if (start || stop)
     hipExtLaunchKernelGGL(blend_bwd_pair_kernel, grid, dim3(128), 0, (hipStream_t)stream, start, stop, 0, W, H,
                           (const uint2*)ranges, point_list, (const uint4*)records, bg, final_T, n_contrib, dL_dpix, dL_dsplat,
@@ -838,6 +844,19 @@ int gsr::blend_fwd(int W, int H, const uint32_t* ranges, const uint32_t* point_l
                    hipStream_t stream) {
   return launch_blend_fwd(W, H, ranges, point_list, records, bg, out_color, final_T, n_contrib, zero_fill, zero_fill_bytes,
                           segments, segment_length, (hipEvent_t)start_event, (hipEvent_t)stop_event, stream);
+}
+
+extern "C" size_t gsr_segments_bytes(int W, int H) { return (W > 0 && H > 0) ? segments_layout(W, H).total : 0; }
+
+extern "C" int gsr_blend_fwd_segments(int W, int H, const uint32_t* ranges, const uint32_t* point_list,
+                                      const uint32_t* records, const float* bg, float* out_color, float* final_T,
+                                      uint32_t* n_contrib, void* segments, size_t segments_bytes, uint32_t N,
+                                      void* start_event, void* stop_event, void* stream) {
+  GSR_REQUIRE(segments != nullptr && W > 0 && H > 0 && segments_bytes >= segments_layout(W, H).total,
+              "blend_fwd_segments: the segments block is missing or smaller than gsr_segments_bytes");
+  const uint32_t length = gsr::segment_length_for(N);
+  return launch_blend_fwd(W, H, ranges, point_list, records, bg, out_color, final_T, n_contrib, nullptr, 0,
+                          length ? segments : nullptr, length, (hipEvent_t)start_event, (hipEvent_t)stop_event, stream);
 }
 
 extern "C" int gsr_blend_bwd_timed(int W, int H, const uint32_t* ranges, const uint32_t* point_list,

@@ -52,6 +52,9 @@ _CARRIED_FILLS = os.environ.get("GSR_SEPARATE_FILLS", "0") in ("", "0")
 # The forward is ONE call into the library (gsr_forward) unless GSR_STAGED=1 or a stage timer is installed;
 # then it is the sequence of stage calls, with the same results bit for bit.
 SINGLE_CALL = os.environ.get("GSR_STAGED", "0") in ("", "0")
+# GSR_NO_SEGMENTS=1, for measurements of the difference: the forward keeps no depth segments for the blend backward
+# (gsr_blend_bwd_segments in gsr.h); the library reads the same variable for the single call.
+_SEGMENTS = os.environ.get("GSR_NO_SEGMENTS") is None
 
 
 class _ForwardArgs(C.Structure):
@@ -119,6 +122,9 @@ def _load():
     lib.gsr_blend_bwd_timed.argtypes = [ci, ci, vp, vp, vp, vp, vp, vp, vp, vp, vp, vp, vp]
     lib.gsr_blend_bwd_fill.argtypes = [ci, ci, vp, vp, vp, vp, vp, vp, vp, vp, vp, vp, C.c_size_t, vp, vp, vp]
     lib.gsr_blend_bwd_segments.argtypes = [ci, ci, vp, vp, vp, vp, vp, vp, vp, vp, vp, vp, C.c_size_t, vp, vp, vp, vp]
+    lib.gsr_segments_bytes.restype = C.c_size_t
+    lib.gsr_segments_bytes.argtypes = [ci, ci]
+    lib.gsr_blend_fwd_segments.argtypes = [ci, ci, vp, vp, vp, vp, vp, vp, vp, vp, C.c_size_t, u32, vp, vp, vp]
     lib.gsr_debug_segments.argtypes, lib.gsr_debug_segments.restype = [u32, u32], None
     lib.gsr_event_create.restype = vp
     lib.gsr_event_create_untimed.restype = vp
@@ -165,7 +171,7 @@ def segment_counts(st) -> tuple:
         return 0, 0, None
     tiles = ((st.W + TILE - 1) // TILE) * ((st.H + TILE - 1) // TILE)
     pad = lambda n: (n + 255) // 256 * 256
-    storage = st.records.untyped_storage()
+    storage = (st.records if st.segments_block is None else st.segments_block).untyped_storage()
     at = st.segments - storage.data_ptr() + SEGMENT_POOL * 4096 + pad(SEGMENT_POOL * 8)
     words = torch.empty(0, dtype=torch.int32, device=st.records.device).set_(storage, at // 4, (pad(tiles * 4) // 4 + 3,))
     host = words.cpu()
@@ -363,7 +369,7 @@ class ForwardState:
     and the intermediate buffers the parity tests inspect."""
     __slots__ = ("P", "M", "D", "W", "H", "records", "radii", "depth_keys", "sorted_vals",
                  "num_rendered", "num_visible", "dsplat", "zeroed_grads", "visible", "point_list", "ranges", "tile_ids_sorted", "color", "final_T", "n_contrib",
-                 "view", "proj", "campos", "bg", "segments")
+                 "view", "proj", "campos", "bg", "segments", "segments_block")
 
     # views into the 64-byte records, named as the oracle names them
     @property
@@ -647,7 +653,7 @@ def rasterize_forward(s: GaussianRasterizationSettings, means3D, opacities, shs=
     st.campos, st.bg = _f32(s.campos, "campos"), _f32(s.bg, "bg")
     st.dsplat = None
     st.zeroed_grads = None
-    st.segments = None
+    st.segments = st.segments_block = None
     ref_lists = int(REFERENCE_LISTS if reference_lists is None else reference_lists)
     # a timer that brackets stages with events needs the stage calls; one that only wants the blend kernels' own
     # events does not
@@ -744,8 +750,19 @@ def rasterize_forward(s: GaussianRasterizationSettings, means3D, opacities, shs=
          _ptr(st.ranges), _ptr(st.tile_ids_sorted), *guards, _ptr(scratch), nb, stream)
     if P > 0 and prepare_backward and _OVERLAP:
         torch.cuda.current_stream(dev).wait_event(cleared)
-    _run_blend("blend_fwd", _lib.gsr_blend_fwd, _lib.gsr_blend_fwd_timed, W, H, _ptr(st.ranges), _ptr(st.point_list),
-               _ptr(st.records), _ptr(st.bg), _ptr(st.color), _ptr(st.final_T), _ptr(st.n_contrib))
+    blend_args = (W, H, _ptr(st.ranges), _ptr(st.point_list), _ptr(st.records), _ptr(st.bg), _ptr(st.color), _ptr(st.final_T),
+                  _ptr(st.n_contrib))
+    if prepare_backward and N > 0 and _SEGMENTS:
+        # depth segments for the backward's long walks (gsr_blend_bwd_segments); the block's last 256 bytes hold its counters
+        nb = _lib.gsr_segments_bytes(W, H)
+        st.segments_block = torch.empty((nb,), dtype=torch.uint8, device=dev)
+        st.segments_block[nb - 256:].zero_()
+        st.segments = st.segments_block.data_ptr()
+        seg = (_ptr(st.segments_block), nb, N)
+        _run_blend("blend_fwd", lambda *a: _lib.gsr_blend_fwd_segments(*a[:-1], None, None, a[-1]), _lib.gsr_blend_fwd_segments,
+                   *blend_args, *seg)
+    else:
+        _run_blend("blend_fwd", _lib.gsr_blend_fwd, _lib.gsr_blend_fwd_timed, *blend_args)
     st.point_list = st.point_list[:N]
     if keep_tile_ids:
         st.tile_ids_sorted = st.tile_ids_sorted[:N]

@@ -366,10 +366,19 @@ int gsr_blend_bwd_fill(int W, int H, const uint32_t* ranges, const uint32_t* poi
  * walked less than 2048 entries deep (every ordinary one) cost the forward nothing and this call a
  * microsecond.  The reference has no counterpart: its backward (diff-gaussian-rasterization,
  * RasterizeGaussiansBackwardCUDA) walks every tile in one block.
+ * For callers of the stage entry points: gsr_blend_fwd_segments is gsr_blend_fwd_timed (events optional) that
+ * also keeps the segments, in a block of gsr_segments_bytes(W, H) bytes (256-byte aligned) whose LAST 256 bytes
+ * the caller has zeroed on `stream`; N = the number of list entries (gsr_bin_lists' N).  A block with those
+ * bytes zero that no forward has written to means "no segments" to gsr_blend_bwd_segments.
  * gsr_debug_segments: from now on, for this process, `entries` instead of 2048 (rounded up to a multiple of
  * 256; 0 = gsr_forward keeps no segments) and a pool of `pool` records (0 = all 8192; with fewer a forward
  * can find the pool empty, and the tiles that come too late are walked whole), for tests of the path on small
  * scenes. */
+size_t gsr_segments_bytes(int W, int H);
+int gsr_blend_fwd_segments(int W, int H, const uint32_t* ranges, const uint32_t* point_list,
+                           const uint32_t* records, const float* bg, float* out_color, float* final_T,
+                           uint32_t* n_contrib, void* segments, size_t segments_bytes, uint32_t N,
+                           void* start_event, void* stop_event, void* stream);
 int gsr_blend_bwd_segments(int W, int H, const uint32_t* ranges, const uint32_t* point_list,
                            const uint32_t* records, const float* bg, const float* final_T,
                            const uint32_t* n_contrib, const float* dL_dpix, float* dL_dsplat,

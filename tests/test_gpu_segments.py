@@ -91,6 +91,28 @@ def test_segmented_backward_against_the_oracle(oracle32, segment_length, name, l
     assert float((again - sums).abs().max()) / scale < 1e-5
 
 
+def test_stage_calls_keep_segments_too(segment_length):
+    """gsr_blend_fwd_segments behind the sequence of stage calls: the same boundaries and sums as the single call."""
+    import diff_gaussian_rasterization as dgr
+    P, W, H, deg, coeffs, bgc, kw = CASES["skewed_hot_tiles_faint"]
+    cloud, cam, bg, mod = make_scene(P, W, H, sh_degree=deg, seed=11, bg=bgc, coeffs=coeffs, **kw)
+    s_gpu, c = _gpu_settings(cam, bg, deg, mod), cloud.to("cuda")
+    dLg = torch.randn(3, H, W, device="cuda", generator=torch.Generator("cuda").manual_seed(4))
+    segment_length(256)
+    one = _forward(dgr, s_gpu, c)
+    staged = dgr.rasterize_forward(s_gpu, c.xyz, c.opacity, shs=c.features, scales=c.scaling, rotations=c.rotation,
+                                   prepare_backward=True, single_call=False)
+    a, la, ta = dgr.segment_counts(one)
+    b, lb, tb = dgr.segment_counts(staged)
+    assert staged.segments_block is not None and (a, la) == (b, lb) and a > 0 and torch.equal(ta, tb)
+    assert torch.equal(one.color, staged.color)
+    sums_one, sums_staged = dgr.blend_backward(one, dLg), dgr.blend_backward(staged, dLg)
+    assert float((sums_one - sums_staged).abs().max()) / float(sums_one.abs().max()) < 1e-5
+    # without a backward to prepare, the stage calls keep none
+    plain = dgr.rasterize_forward(s_gpu, c.xyz, c.opacity, shs=c.features, scales=c.scaling, rotations=c.rotation, single_call=False)
+    assert plain.segments is None
+
+
 def test_the_pool_running_dry_only_ends_the_cutting(segment_length):
     """More boundaries than the pool has dumps (the library sizes its segments so that this cannot happen; the test
     shrinks the pool): the tiles that come too late are walked whole, the sums are the same."""
@@ -141,6 +163,29 @@ def test_segments_grow_with_the_lists_so_that_the_pool_holds_every_boundary(segm
     assert asked == int(per_tile.sum()) <= dgr.SEGMENT_POOL
     lengths = (st.ranges[:, 1] - st.ranges[:, 0]).cpu()
     assert bool((per_tile <= lengths // used_length).all())
+
+
+def test_the_library_s_own_segment_length_against_the_oracle(oracle32):
+    """48 000 faint Gaussians over four tiles: walks 48 000 entries deep, cut every 2048 entries as shipped."""
+    import diff_gaussian_rasterization as dgr
+    P, W, H = 48_000, 96, 64
+    cloud, cam, bg, mod = make_scene(P, W, H, sh_degree=0, seed=6, coeffs=1, skew_fraction=1.0, distance=30.0, opacity_const=0.004)
+    s_cpu, cn = oracle_settings(cam, bg, 0, mod), cloud_numpy(cloud)
+    ref = oracle32.forward(s_cpu, **cn)
+    s_gpu, c = _gpu_settings(cam, bg, 0, mod), cloud.to("cuda")
+    safe = ref["fwd"]["margin"] >= MARGIN_SAFE
+    dL = np.random.default_rng(8).standard_normal((3, H, W)).astype(np.float32) * safe[None]
+    dLg = torch.from_numpy(dL).cuda()
+    st = _forward(dgr, s_gpu, c)
+    asked, length, per_tile = dgr.segment_counts(st)
+    print("deepest walk", int(st.n_contrib.max()), "segments of", length, "boundaries", asked, flush=True)
+    assert length == 2048 and int(per_tile.max()) >= 20
+    assert np.abs(st.color.cpu().numpy() - ref["color"])[:, safe].max() <= PIX_TOL
+    g, ds, _ = _backward(dgr, s_gpu, st, dLg, c)
+    blend, full, _ = _backward_errors(oracle32, s_cpu, cn, ref, dL, g, ds)
+    print({k: "%.1e" % v for k, v in {**blend, **full}.items()}, flush=True)
+    assert all(e < 2e-5 for e in blend.values()), blend
+    assert all(e < 3e-5 for e in full.values()), full
 
 
 def test_default_length_leaves_ordinary_scenes_alone():
