@@ -197,7 +197,11 @@ __global__ void __launch_bounds__(256) blend_fwd_kernel(int W, int H, const uint
 
   const Pixel px = my_pixel(W, H);
   const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
-  const float pxf = (float)px.x, pyf = (float)px.y;
+  // The pixel's coordinates as floats are what the splat loop uses; pinned in registers here, because with the
+  // integer coordinates also wanted after the loop the compiler otherwise keeps only those and converts them
+  // again for every splat (two of the loop's thirty vector instructions).  The integers are recomputed at the end.
+  float pxf = (float)px.x, pyf = (float)px.y;
+  asm volatile("" : "+v"(pxf), "+v"(pyf));
   const float tx0 = (float)(blockIdx.x * GSR_TILE_X), ty0 = (float)(blockIdx.y * GSR_TILE_Y);
   const uint2 range = ranges[blockIdx.y * gridDim.x + blockIdx.x];
   const int total = (int)(range.y - range.x);
@@ -215,11 +219,17 @@ __global__ void __launch_bounds__(256) blend_fwd_kernel(int W, int H, const uint
   const int seg_rounds = (int)(seg.length / kBatch);
   int next_dump = seg_rounds ? seg_rounds : 0x7fffffff, dumps = 0;
   const uint32_t tile = blockIdx.y * gridDim.x + blockIdx.x;
-  const int in_tile = (px.y - (int)blockIdx.y * GSR_TILE_Y) * GSR_TILE_X + (px.x - (int)blockIdx.x * GSR_TILE_X);
+  // (recomputed from the thread index where it is needed: a value kept alive through the splat loop for these rare
+  // uses costs the loop two instructions per splat, the compiler then rematerialises the pixel's coordinates there)
+  auto in_tile = [] {
+    const int w = threadIdx.x >> 6, l = threadIdx.x & 63;
+    return ((w >> 1) * 8 + (l >> 3)) * GSR_TILE_X + (w & 1) * 8 + (l & 7);
+  };
 
   for (int b = 0; b < rounds; b++) {
     const bool wave_done = __ballot(accept < __builtin_inff()) == 0ull;
     if (__syncthreads_and(wave_done)) break;   // also fences the previous batch's LDS reads
+#ifndef GSR_EXPERIMENT_NO_FWD_DUMPS
     if (b == next_dump) {                      // some pixel is still open at a segment boundary
       if (threadIdx.x == 0) {
         const uint32_t slot = atomicAdd(seg.head, 1u);
@@ -229,13 +239,14 @@ __global__ void __launch_bounds__(256) blend_fwd_kernel(int W, int H, const uint
       __syncthreads();
       const uint32_t slot = s_slot[dumps];
       if (slot < seg.cap) {
-        seg.dumps[(size_t)slot * 256 + in_tile] = make_float4(T, C0, C1, C2);
+        seg.dumps[(size_t)slot * 256 + in_tile()] = make_float4(T, C0, C1, C2);
         dumps++;
         next_dump = dumps < kMaxTileDumps ? next_dump + seg_rounds : 0x7fffffff;
       } else {
         next_dump = 0x7fffffff;                // the pool is empty: the tile's own backward workgroup walks the rest
       }
     }
+#endif
 
     // stage one batch
     const int s = b * kBatch + (int)threadIdx.x;
@@ -293,11 +304,12 @@ __global__ void __launch_bounds__(256) blend_fwd_kernel(int W, int H, const uint
     }
   }
 
+#ifndef GSR_EXPERIMENT_NO_FWD_DUMPS
   if (seg.length) {
     // what the backward wants of a dump is the colour composited at and behind the boundary: the final sums
     // minus the sums in front of it (each thread rewrites its own words)
     for (int k = 0; k < dumps; k++) {
-      float4* d = seg.dumps + (size_t)s_slot[k] * 256 + in_tile;
+      float4* d = seg.dumps + (size_t)s_slot[k] * 256 + in_tile();
       const float4 v = *d;
       *d = make_float4(v.x, C0 - v.y, C1 - v.z, C2 - v.w);
     }
@@ -306,8 +318,12 @@ __global__ void __launch_bounds__(256) blend_fwd_kernel(int W, int H, const uint
       if (tile == 0) { seg.head[1] = seg.length; seg.head[2] = seg.cap; }
     }
   }
-  if (px.inside) {
-    const size_t pix = (size_t)px.y * W + px.x, plane = (size_t)W * H;
+#endif
+  int t = (int)threadIdx.x;
+  asm volatile("" : "+v"(t));
+  const int ox = (int)blockIdx.x * GSR_TILE_X + ((t >> 6) & 1) * 8 + (t & 7), oy = (int)blockIdx.y * GSR_TILE_Y + (t >> 7) * 8 + ((t & 63) >> 3);
+  if (ox < W && oy < H) {
+    const size_t pix = (size_t)oy * W + ox, plane = (size_t)W * H;
     final_T[pix] = T;
     n_contrib[pix] = last;
     out_color[pix] = C0 + T * bg[0];
