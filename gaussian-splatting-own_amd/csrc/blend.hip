@@ -88,12 +88,17 @@ __device__ __forceinline__ unsigned long long lds_mask(const unsigned long long*
   return ((unsigned long long)hi << 32) | lo;
 }
 
-// Exponent of the Gaussian in the log2 domain, la*dx^2 + lc*dy^2 + lb*dx*dy with
-// (la, lb, lc) = (-A/2, -B, -C/2) * log2(e).  Forward and backward MUST take the
-// same skip / keep decisions per (splat, pixel), so both call this one function
-// and the rounding sequence is pinned with explicit fma.
+// Exponent of the Gaussian in the log2 domain, la*dx^2 + lb*dx*dy + lc*dy^2 with
+// (la, lb, lc) = (-A/2, -B, -C/2) * log2(e), evaluated as dx * (la*dx + lb*dy) + (lc*dy)*dy: five
+// operations, and of those the two products with dy alone are shared by pixels of the same row (the two
+// pixels of a lane of the backward).  Forward and backward MUST take the same skip / keep decisions per
+// (splat, pixel), so both go through these functions and the rounding sequence is pinned with explicit fma.
+__device__ __forceinline__ float gauss_exponent_row(float lc, float dy) { return (lc * dy) * dy; }
+__device__ __forceinline__ float gauss_exponent(float la, float lb_dy, float lc_dy_dy, float dx) {
+  return fmaf(dx, fmaf(la, dx, lb_dy), lc_dy_dy);
+}
 __device__ __forceinline__ float gauss_exponent(float la, float lb, float lc, float dx, float dy) {
-  return fmaf(lb * dx, dy, fmaf(la * dx, dx, (lc * dy) * dy));
+  return gauss_exponent(la, lb * dy, gauss_exponent_row(lc, dy), dx);
 }
 
 // What a staging thread publishes about one splat: one 48-byte LDS slot, so that the waves reading it
@@ -659,7 +664,8 @@ __global__ void __launch_bounds__(128) blend_bwd_pair_kernel(int W, int H, const
         const float4 geo = s_splat.geo[j], col = s_splat.col[j];
         // the same subtractions and the same exponent as the forward's, per pixel
         const float dxa = geo.x - x0f, dxb = geo.x - x1f, dy = geo.y - yf;
-        const float pa = gauss_exponent(geo.z, geo.w, col.x, dxa, dy), pb = gauss_exponent(geo.z, geo.w, col.x, dxb, dy);
+        const float row = gauss_exponent_row(col.x, dy), lb_dy = geo.w * dy;
+        const float pa = gauss_exponent(geo.z, lb_dy, row, dxa), pb = gauss_exponent(geo.z, lb_dy, row, dxb);
         float oGa = col.y * __builtin_amdgcn_exp2f(pa), oGb = col.y * __builtin_amdgcn_exp2f(pb);
         const bool hita = (pa <= 0.0f) & (oGa >= GSR_ALPHA_MIN) & (pos < last0);
         const bool hitb = (pb <= 0.0f) & (oGb >= GSR_ALPHA_MIN) & (pos < last1);

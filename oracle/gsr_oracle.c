@@ -88,7 +88,7 @@ static inline REAL gauss_value(REAL A, REAL B, REAL Cc, REAL dx, REAL dy, REAL* 
 #ifdef GSO_KERNEL_ORDER
   const REAL log2e = K(1.4426950408889634);
   const REAL la = (K(-0.5) * log2e) * A, lb = (-log2e) * B, lc = (K(-0.5) * log2e) * Cc;
-  const REAL p2 = r_fma(lb * dx, dy, r_fma(la * dx, dx, (lc * dy) * dy));
+  const REAL p2 = r_fma(dx, r_fma(la, dx, lb * dy), (lc * dy) * dy);
   *power = p2 * K(0.6931471805599453);
   return r_exp2(p2);
 #else
