@@ -627,6 +627,9 @@ __global__ void __launch_bounds__(128) blend_bwd_pair_kernel(int W, int H, const
   const float4* const red_lo = reinterpret_cast<const float4*>(s_red[wave] + my_row * kRedStride + my_first + my_seg);
   const float4* const red_hi = reinterpret_cast<const float4*>(s_red[wave] + my_row * kRedStride + (my_first ^ 32) + my_seg);
 
+  const bool ninth = lane == 1, adds = (lane & 7) == 0 || ninth;     // lanes 0, 8, .., 56 hold sums 0..7, lane 1 the ninth
+  const int my_word = ninth ? 8 : (lane >> 3);
+
   for (int b = (tile_last - 1) / kPairBatch; b >= lo / kPairBatch; b--) {
     __syncthreads();
     const int s = b * kPairBatch + (int)threadIdx.x;
@@ -696,9 +699,9 @@ __global__ void __launch_bounds__(128) blend_bwd_pair_kernel(int W, int H, const
         v = dpp_add<0xB1>(v); v = dpp_add<0x4E>(v); v = dpp_add<0x141>(v);
         v8 = dpp_add<0xB1>(v8); v8 = dpp_add<0x4E>(v8); v8 = dpp_add<0x141>(v8); v8 = dpp_add<0x140>(v8);
         v8 = sum_across_rows(v8);
-        const bool ninth = lane == 1;
-        if ((lane & 7) == 0 || ninth)
-          atomicAdd(dL_dsplat + (size_t)__float_as_uint(bi.y) * GSR_GRAD_WORDS + (ninth ? 8 : (lane >> 3)), ninth ? v8 : v);
+        // the row's address as a scalar (every lane holds the same index), the lane's word as a constant offset
+        float* const grad_row = dL_dsplat + (size_t)(uint32_t)__builtin_amdgcn_readfirstlane(__float_as_uint(bi.y)) * GSR_GRAD_WORDS;
+        if (adds) atomicAdd(grad_row + my_word, ninth ? v8 : v);
       }
     }
   }
