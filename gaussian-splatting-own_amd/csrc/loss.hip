@@ -136,7 +136,13 @@ __device__ __forceinline__ TileWalk make_walk(int H, int W, int C) {
 }
 
 // block = 256 threads; a fixed number of blocks walks all (tile, channel) pairs
-__global__ void __launch_bounds__(256) loss_fwd_kernel(int H, int W, int C, const float* __restrict__ img,
+#ifndef GSR_LOSS_FWD_PER_CU
+#define GSR_LOSS_FWD_PER_CU 5
+#endif
+#ifndef GSR_LOSS_BWD_PER_CU
+#define GSR_LOSS_BWD_PER_CU 4
+#endif
+__global__ void __launch_bounds__(256, GSR_LOSS_FWD_PER_CU) loss_fwd_kernel(int H, int W, int C, const float* __restrict__ img,
                                                        const float* __restrict__ gt, Window win,
                                                        float* __restrict__ dmaps, float* __restrict__ partial) {
   // x, y, xx + yy, xy after the horizontal pass
@@ -261,7 +267,7 @@ __global__ void __launch_bounds__(1024) loss_finalize_kernel(int nblocks, const 
   }
 }
 
-__global__ void __launch_bounds__(256) loss_bwd_kernel(int H, int W, int C, const float* __restrict__ img,
+__global__ void __launch_bounds__(256, GSR_LOSS_BWD_PER_CU) loss_bwd_kernel(int H, int W, int C, const float* __restrict__ img,
                                                        const float* __restrict__ gt, const float* __restrict__ dmaps,
                                                        Window win, const float* __restrict__ grad_out, float lambda,
                                                        float inv_n, float* __restrict__ grad_img) {
@@ -354,7 +360,7 @@ int loss_blocks(int C, int H, int W, int per_cu) {
   const int cap = 256 * per_cu;
   return tiles < cap ? tiles / 8 * 8 : cap;
 }
-constexpr int kFwdPerCu = 5, kBwdPerCu = 4;   // resident blocks per CU (registers forward, LDS backward)
+constexpr int kFwdPerCu = GSR_LOSS_FWD_PER_CU, kBwdPerCu = GSR_LOSS_BWD_PER_CU;   // resident blocks per CU (registers forward, LDS backward)
 
 }  // namespace
 
