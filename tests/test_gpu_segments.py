@@ -188,6 +188,38 @@ def test_the_library_s_own_segment_length_against_the_oracle(oracle32):
     assert all(e < 3e-5 for e in full.values()), full
 
 
+def test_full_size_after_opacity_reset_segments_match_whole_walks(segment_length):
+    """The benchmark's c5r workload (6M Gaussians, half of them in a hot spot, every opacity 0.01 as after the
+    reference's reset_opacity, scene/gaussian_model.py:210-213; 1920x1080): as shipped the backward cuts its deepest
+    walks (45,000 entries) into segments of N / 8192 entries; the sums are those of whole walks."""
+    import diff_gaussian_rasterization as dgr
+    W, H, deg = 1920, 1080, 3
+    cloud, cam, bg, mod = make_scene(6_000_000, W, H, sh_degree=deg, seed=0, skew_fraction=0.5, opacity_const=0.01)
+    s_gpu, c = _gpu_settings(cam, bg, deg, mod), cloud.to("cuda")
+    del cloud
+    dLg = torch.randn(3, H, W, device="cuda", generator=torch.Generator("cuda").manual_seed(6)) / (3 * H * W)
+    st = _forward(dgr, s_gpu, c)
+    asked, length, per_tile = dgr.segment_counts(st)
+    deepest = int(st.n_contrib.max())
+    print("entries", st.num_rendered, "deepest walk", deepest, "segments of", length, "boundaries", asked, "most in one tile",
+          int(per_tile.max()), flush=True)
+    assert length == (st.num_rendered // dgr.SEGMENT_POOL + 256) // 256 * 256 > 2048
+    assert asked == int(per_tile.sum()) and int(per_tile.max()) == (deepest - 1) // length >= 4
+    sums = dgr.blend_backward(st, dLg).clone()
+    color = st.color.clone()
+    del st
+    segment_length(0)
+    whole = _forward(dgr, s_gpu, c)
+    assert whole.segments is None and torch.equal(whole.color, color)
+    sums_whole = dgr.blend_backward(whole, dLg)
+    scale = float(sums_whole.abs().max())
+    apart = float((sums - sums_whole).abs().max()) / scale
+    print("per-Gaussian sums, segmented vs whole walks: %.2e of the largest" % apart, flush=True)
+    assert apart < 2e-5
+    del whole, sums, sums_whole, c
+    torch.cuda.empty_cache()
+
+
 def test_default_length_leaves_ordinary_scenes_alone():
     """At the library's own segment length an ordinary scene takes no dump: the backward is the whole-walk one."""
     import diff_gaussian_rasterization as dgr
