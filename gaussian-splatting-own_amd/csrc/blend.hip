@@ -107,16 +107,16 @@ struct __align__(16) Staged {
   float4 geo;      // x, y, la, lb
   float4 col;      // lc, opacity, r, g
   float blue;
-  uint32_t id;     // Gaussian index (backward only)
+  uint32_t tag;    // whatever the walk wants back with the splat (the forward: its 1-based position in the tile's list)
   float pad[2];
 };
 
-__device__ __forceinline__ void stage_record(Staged* slot, const uint4 r0, const uint4 r1, const uint4 r2, uint32_t id) {
+__device__ __forceinline__ void stage_record(Staged* slot, const uint4 r0, const uint4 r1, const uint4 r2, uint32_t tag) {
   slot->geo = make_float4(__uint_as_float(r0.x), __uint_as_float(r0.y), -0.5f * kLog2e * __uint_as_float(r1.x),
                           -kLog2e * __uint_as_float(r1.y));
   slot->col = make_float4(-0.5f * kLog2e * __uint_as_float(r1.z), __uint_as_float(r1.w), __uint_as_float(r2.x),
                           __uint_as_float(r2.y));
-  *reinterpret_cast<float2*>(&slot->blue) = make_float2(__uint_as_float(r2.z), __uint_as_float(id));
+  *reinterpret_cast<float2*>(&slot->blue) = make_float2(__uint_as_float(r2.z), __uint_as_float(tag));
 }
 
 // The backward's staging: the same ten words without the padding (the 2 KB saved per workgroup are what lets a
@@ -263,7 +263,7 @@ __global__ void __launch_bounds__(256) blend_fwd_kernel(int W, int H, const uint
       const float sx = __uint_as_float(r0.x), sy = __uint_as_float(r0.y);
       qm = quadrant_mask(sx, sy, __uint_as_float(r0.z), __uint_as_float(r0.w), __uint_as_float(r1.x),
                          __uint_as_float(r1.y), __uint_as_float(r1.z), __uint_as_float(r1.w), tx0, ty0);
-      stage_record(&s_splat[threadIdx.x], r0, r1, r2, g);
+      stage_record(&s_splat[threadIdx.x], r0, r1, r2, (uint32_t)s + 1u);
     }
 #pragma unroll
     for (int q = 0; q < 4; q++) {
@@ -282,7 +282,8 @@ __global__ void __launch_bounds__(256) blend_fwd_kernel(int W, int H, const uint
           const Staged* sp = &s_splat[j];
           const float4 ga = sp->geo;
           const float4 co = sp->col;
-          const float blue = sp->blue;
+          const float2 tail = *reinterpret_cast<const float2*>(&sp->blue);   // blue, position (one 8-byte read)
+          const float blue = tail.x;
           const float dx = ga.x - pxf, dy = ga.y - pyf;
           const float p = gauss_exponent(ga.z, ga.w, co.x, dx, dy);
           // alpha = min(.99, oG) is kept iff the exponent is <= 0 and alpha >= 1/255, i.e. oG >= 1/255
@@ -302,7 +303,7 @@ __global__ void __launch_bounds__(256) blend_fwd_kernel(int W, int H, const uint
           C0 = fmaf(co.z, w, C0);
           C1 = fmaf(co.w, w, C1);
           C2 = fmaf(blue, w, C2);
-          last = blend ? (uint32_t)(b * kBatch + j + 1) : last;
+          last = blend ? __float_as_uint(tail.y) : last;
         }
         if (__ballot(accept < __builtin_inff()) == 0ull) break;
       }
