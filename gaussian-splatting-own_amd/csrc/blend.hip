@@ -70,7 +70,8 @@ __device__ __forceinline__ unsigned quadrant_mask(float sx, float sy, float hx, 
   unsigned m = (unsigned)(xl && yt) | ((unsigned)(xr && yt) << 1) | ((unsigned)(xl && yb) << 2) | ((unsigned)(xr && yb) << 3);
   if (m == 0u) return 0u;
   const float tau = 2.0f * __logf(255.0f * o) * 1.001f + 0.01f;
-  const float nBA = -B / A, nBC = -B / C;
+  // (hardware reciprocals: the test only has to err on the side of "reaches", which tau's margin takes care of)
+  const float nBA = -B * __builtin_amdgcn_rcpf(A), nBC = -B * __builtin_amdgcn_rcpf(C);
   const float ax0 = tx0 - sx, ay0 = ty0 - sy;
   unsigned e = 0u;
 #pragma unroll
