@@ -1,5 +1,5 @@
 #!/bin/bash
-# Round 3, first GPU call: the whole GPU suite on the default kernels, the backward parity tests and the blend
+# First GPU call: the whole GPU suite on the default kernels, the backward parity tests and the blend
 # timings under each formulation of the blend backward (GSR_BLEND_BWD).
 set -e
 cd $GRAFT_REPO_ROOT

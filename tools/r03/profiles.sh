@@ -1,5 +1,5 @@
 #!/bin/bash
-# Round 3 profiles: kernel trace + counter passes on C3 and c3w, kernel traces of C5, C2, c5w, c5r and of the step through
+# The profile set: kernel trace + counter passes on C3 and c3w, kernel traces of C5, C2, c5w, c5r and of the step through
 # the reference's operator API, then the default benchmark line.
 set -e
 cd $GRAFT_REPO_ROOT
