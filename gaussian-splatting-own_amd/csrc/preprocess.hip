@@ -656,20 +656,41 @@ __device__ __forceinline__ void bwd_one_gaussian(const BwdArgs& a, const int i, 
   if (SPARSE) {
     // the outputs were zero when the kernel started: only the Gaussians with gradients write, each its own rows
     if (!vis) return;
+    // 16 bytes per store wherever the row allows it (dword alignment is all a global store needs): every store of a
+    // lane goes to a line of its own here, and 48 stores of 4 bytes per lane were most of the kernel's requests
     if (a.dL_dshs_rest) {
       const int R = a.n_rest * 3;
       float* dst = a.dL_dshs_rest + (size_t)i * R;
 #pragma unroll
-      for (int k = 3; k < 48; k++)
-        if (k - 3 < R) dst[k - 3] = dsh[k];
+      for (int k = 0; k < 44; k += 4) {
+        if (k + 3 < R) {
+          float4u v;
+          v.x = dsh[3 + k]; v.y = dsh[4 + k]; v.z = dsh[5 + k]; v.w = dsh[6 + k];
+          *reinterpret_cast<float4u*>(dst + k) = v;
+        } else {
+#pragma unroll
+          for (int j = 0; j < 4; j++)
+            if (k + j < R) dst[k + j] = dsh[3 + k + j];
+        }
+      }
+      if (44 < R) dst[44] = dsh[47];
       float* dc = a.dL_dshs + (size_t)i * 3;
       dc[0] = dsh[0]; dc[1] = dsh[1]; dc[2] = dsh[2];
     } else if (a.dL_dshs) {
       const int R = a.M * 3;
       float* dst = a.dL_dshs + (size_t)i * R;
 #pragma unroll
-      for (int k = 0; k < 48; k++)
-        if (k < R) dst[k] = dsh[k];
+      for (int k = 0; k < 48; k += 4) {
+        if (k + 3 < R) {
+          float4u v;
+          v.x = dsh[k]; v.y = dsh[k + 1]; v.z = dsh[k + 2]; v.w = dsh[k + 3];
+          *reinterpret_cast<float4u*>(dst + k) = v;
+        } else {
+#pragma unroll
+          for (int j = 0; j < 4; j++)
+            if (k + j < R) dst[k + j] = dsh[k + j];
+        }
+      }
     }
   } else if (a.dL_dshs_rest) {
     // each lane puts its row into the LDS tile, then the block stores the tile fully coalesced
