@@ -2,6 +2,8 @@
 workgroups, each from the state the forward wrote down at a segment boundary.  The library's own segment
 length (2048 entries) is beyond what small test scenes reach, so the tests lower it; the results must be the
 oracle's at the ordinary bars, and those of whole walks up to rounding."""
+import os
+
 import numpy as np
 import pytest
 import torch
@@ -9,7 +11,8 @@ import torch
 from scenes import cloud_numpy, make_scene, oracle_settings
 from test_gpu_parity import GRADS, MARGIN_SAFE, PIX_TOL, _backward_errors, _gpu_settings
 
-pytestmark = pytest.mark.gpu
+pytestmark = [pytest.mark.gpu,
+              pytest.mark.skipif(os.environ.get("GSR_NO_SEGMENTS") is not None, reason="GSR_NO_SEGMENTS switches the segments off")]
 
 # name: (P, W, H, degree, coeffs, bg, kwargs): faint splats, so that the walks go deep; one tile, hot tiles, all tiles
 CASES = {
@@ -28,8 +31,9 @@ def segment_length():
 
 
 def _forward(dgr, s_gpu, c):
+    # (the module's own lists, whatever GSR_SHORT_LISTS says: the scenes' walk depths are chosen for them)
     st = dgr.rasterize_forward(s_gpu, c.xyz, c.opacity, shs=c.features, scales=c.scaling, rotations=c.rotation,
-                               prepare_backward=True, single_call=True)
+                               prepare_backward=True, single_call=True, reference_lists=True)
     torch.cuda.synchronize()
     return st
 
@@ -101,7 +105,7 @@ def test_stage_calls_keep_segments_too(segment_length):
     segment_length(256)
     one = _forward(dgr, s_gpu, c)
     staged = dgr.rasterize_forward(s_gpu, c.xyz, c.opacity, shs=c.features, scales=c.scaling, rotations=c.rotation,
-                                   prepare_backward=True, single_call=False)
+                                   prepare_backward=True, single_call=False, reference_lists=True)
     a, la, ta = dgr.segment_counts(one)
     b, lb, tb = dgr.segment_counts(staged)
     assert staged.segments_block is not None and (a, la) == (b, lb) and a > 0 and torch.equal(ta, tb)
