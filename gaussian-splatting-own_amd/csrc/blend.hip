@@ -382,15 +382,23 @@ __device__ __forceinline__ float dpp_add(float v) {
   return v + __int_as_float(moved);
 }
 
-typedef unsigned uint2v __attribute__((ext_vector_type(2)));
-
-// Sum over the four rows of a wave, lane-wise: lane l ends with v[l%16] summed over the rows.
-// v_permlane16_swap / v_permlane32_swap exchange odd and even rows, then the two 32-lane halves.
-__device__ __forceinline__ float sum_across_rows(float v) {
-  uint2v r = __builtin_amdgcn_permlane16_swap(__float_as_uint(v), __float_as_uint(v), false, false);
-  v = __uint_as_float(r.x) + __uint_as_float(r.y);
-  r = __builtin_amdgcn_permlane32_swap(__float_as_uint(v), __float_as_uint(v), false, false);
-  return __uint_as_float(r.x) + __uint_as_float(r.y);
+// Sum over the wave's 64 lanes with DPP alone: four steps inside the rows of 16 lanes, then lane 15 of every row
+// added into the row behind it, then lane 31 into the two rows behind it: the lanes of the LAST row (48..63) end
+// with the wave's total.
+__device__ __forceinline__ float sum_into_last_row(float v) {
+  v = v + __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v), 0xB1, 0xf, 0xf, false));    // quad_perm [1,0,3,2]
+  v = v + __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v), 0x4E, 0xf, 0xf, false));    // quad_perm [2,3,0,1]
+  v = v + __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v), 0x141, 0xf, 0xf, false));   // row_half_mirror
+  v = v + __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v), 0x140, 0xf, 0xf, false));   // row_mirror
+  // the two broadcast steps by hand: through the builtin each comes out as three instructions (a zero, a move,
+  // an addition).  Two wait states between a vector write of a register and a DPP read of it.
+  asm volatile(
+      "s_nop 1\n\t"
+      "v_add_f32_dpp %0, %0, %0 row_bcast:15 row_mask:0xa bank_mask:0xf\n\t"
+      "s_nop 1\n\t"
+      "v_add_f32_dpp %0, %0, %0 row_bcast:31 row_mask:0xc bank_mask:0xf"
+      : "+v"(v));
+  return v;
 }
 
 __global__ void __launch_bounds__(256) blend_bwd_kernel(int W, int H, const uint2* __restrict__ ranges,
@@ -507,7 +515,8 @@ __global__ void __launch_bounds__(256) blend_bwd_kernel(int W, int H, const uint
         // (conflict-free), then lane 8k+s adds up eight elements of row k, fetched with two 16-byte
         // reads (conflict-free in the order chosen above), and three DPP steps combine the
         // eight lanes of a row.  The ninth sum stays in registers: four DPP steps within the rows of
-        // 16 lanes, two lane-permute swaps across them.  A wave's LDS operations execute in order, so
+        // 16 lanes, two row-broadcast DPP steps across them (sum_into_last_row; two v_permlane swaps and their
+        // additions here cost the two-pixel kernel 6 % of its time).  A wave's LDS operations execute in order, so
         // no barrier is needed.  (Pairing the eight values through v_permlane32_swap / v_permlane16_swap
         // instead, one swap and one add per pair and level, then four DPP steps on the two registers left,
         // needs no LDS at all and takes the kernel from 0.30 to 0.40 ms: a swap costs over ten cycles.)
@@ -516,11 +525,10 @@ __global__ void __launch_bounds__(256) blend_bwd_kernel(int W, int H, const uint
         float v = ((a0.x + a0.y) + (a0.z + a0.w)) + ((a1.x + a1.y) + (a1.z + a1.w));
         float v8 = dch * dp2;
         v = dpp_add<0xB1>(v); v = dpp_add<0x4E>(v); v = dpp_add<0x141>(v);       // over the 8 segment lanes
-        v8 = dpp_add<0xB1>(v8); v8 = dpp_add<0x4E>(v8); v8 = dpp_add<0x141>(v8); v8 = dpp_add<0x140>(v8);
-        v8 = sum_across_rows(v8);
-        // lane 8k holds sum k (k < 8), every lane holds sum 8: lanes 0,8,..,56 and lane 1 issue ONE
+        v8 = sum_into_last_row(v8);
+        // lane 8k holds sum k (k < 8), the lanes of the last row hold sum 8: lanes 0,8,..,56 and lane 57 issue ONE
         // wave-instruction on nine consecutive dwords of one 64-byte row = one atomic request
-        const bool ninth = lane == 1;
+        const bool ninth = lane == 57;
         if ((lane & 7) == 0 || ninth)
           atomicAdd(dL_dsplat + (size_t)__float_as_uint(bi.y) * GSR_GRAD_WORDS + (ninth ? 8 : (lane >> 3)), ninth ? v8 : v);
       }
@@ -629,7 +637,7 @@ __global__ void __launch_bounds__(128) blend_bwd_pair_kernel(int W, int H, const
   const float4* const red_lo = reinterpret_cast<const float4*>(s_red[wave] + my_row * kRedStride + my_first + my_seg);
   const float4* const red_hi = reinterpret_cast<const float4*>(s_red[wave] + my_row * kRedStride + (my_first ^ 32) + my_seg);
 
-  const bool ninth = lane == 1, adds = (lane & 7) == 0 || ninth;     // lanes 0, 8, .., 56 hold sums 0..7, lane 1 the ninth
+  const bool ninth = lane == 57, adds = (lane & 7) == 0 || ninth;    // lanes 0, 8, .., 56 hold sums 0..7, the last row's lanes the ninth
   const int my_word = ninth ? 8 : (lane >> 3);
 
   for (int b = (tile_last - 1) / kPairBatch; b >= lo / kPairBatch; b--) {
@@ -699,8 +707,10 @@ __global__ void __launch_bounds__(128) blend_bwd_pair_kernel(int W, int H, const
         float v = ((a0.x + a0.y) + (a0.z + a0.w)) + ((a1.x + a1.y) + (a1.z + a1.w));
         float v8 = fmaf(wb, b1, wa * b0);
         v = dpp_add<0xB1>(v); v = dpp_add<0x4E>(v); v = dpp_add<0x141>(v);
-        v8 = dpp_add<0xB1>(v8); v8 = dpp_add<0x4E>(v8); v8 = dpp_add<0x141>(v8); v8 = dpp_add<0x140>(v8);
-        v8 = sum_across_rows(v8);
+        // (the sum is wanted by a few lanes only, and left to itself the compiler moves the last addition behind
+        // their branch, where it cannot be part of the cross-lane instruction any more: three instructions for one)
+        asm volatile("" : "+v"(v));
+        v8 = sum_into_last_row(v8);
         // the row's address as a scalar (every lane holds the same index), the lane's word as a constant offset
         float* const grad_row = dL_dsplat + (size_t)(uint32_t)__builtin_amdgcn_readfirstlane(__float_as_uint(bi.y)) * GSR_GRAD_WORDS;
         if (adds) atomicAdd(grad_row + my_word, ninth ? v8 : v);
