@@ -391,12 +391,7 @@ __global__ void __launch_bounds__(Level<1>::kThreads) write1_kernel(LevelArgs a)
   for (int q = 0; q < kPerWave; q++) {
     const int f = wave * kPerWave + q;
     const uint32_t c = lane < kSteps1 ? s_base[lane][f] : 0u;
-    uint32_t inc = c;
-#pragma unroll
-    for (int o = 1; o < kSteps1; o <<= 1) {
-      const uint32_t u = __shfl_up(inc, o);
-      if (lane >= o) inc += u;
-    }
+    const uint32_t inc = gsr::wave_inclusive_sum(c);       // lanes from kSteps1 on hold zeros
     const uint32_t first = (uint32_t)__shfl((int)piece_pos, q);
     if (lane < kSteps1) s_base[lane][f] = first + inc - c;
   }
@@ -444,12 +439,7 @@ __device__ uint32_t block_scan_inplace(uint32_t* a, uint32_t n, uint32_t* s_wave
       }
       s += v[k].x + v[k].y + v[k].z + v[k].w;
     }
-    uint32_t inc = s;
-#pragma unroll
-    for (int o = 1; o < 64; o <<= 1) {
-      const uint32_t u = __shfl_up(inc, o);
-      if (lane >= o) inc += u;
-    }
+    const uint32_t inc = gsr::wave_inclusive_sum(s);
     if (lane == 63) s_wave[w] = inc;
     __syncthreads();
     uint32_t before = 0, tot = 0;
@@ -511,12 +501,7 @@ __device__ uint32_t block_scan_lds(uint32_t* a, uint32_t n, uint32_t* s_wave) {
   uint32_t v[4], s = 0;
 #pragma unroll
   for (int k = 0; k < 4; k++) { v[k] = i0 + k < n ? a[i0 + k] : 0u; s += v[k]; }
-  uint32_t inc = s;
-#pragma unroll
-  for (int o = 1; o < 64; o <<= 1) {
-    const uint32_t u = __shfl_up(inc, o);
-    if (lane >= o) inc += u;
-  }
+  const uint32_t inc = gsr::wave_inclusive_sum(s);
   __syncthreads();
   if (lane == 63) s_wave[w] = inc;
   __syncthreads();

@@ -99,15 +99,7 @@ __device__ __forceinline__ uint32_t valid_keys(const uint32_t* __restrict__ ctl)
   return n;
 }
 
-__device__ __forceinline__ uint32_t wave_incl_scan(uint32_t v) {
-  const int lane = threadIdx.x & 63;
-#pragma unroll
-  for (int o = 1; o < 64; o <<= 1) {
-    const uint32_t n = __shfl_up(v, o);
-    if (lane >= o) v += n;
-  }
-  return v;
-}
+__device__ __forceinline__ uint32_t wave_incl_scan(uint32_t v) { return gsr::wave_inclusive_sum(v); }
 
 // Clears the histograms, control words and look-back states.  With a mirror, the first workgroup first
 // finishes the list sizes of the preprocess and sends them to the host (see SortMirror): the read-back then

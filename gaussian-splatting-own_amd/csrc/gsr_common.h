@@ -99,6 +99,21 @@ __device__ __forceinline__ uint32_t sum_totals(int blocks, const uint32_t* __res
   return mine;
 }
 
+// Inclusive prefix sum over the 64 lanes of a wave with DPP alone: row_shr 1, 2, 4, 8 inside the rows of 16 lanes
+// (lanes whose source lies outside their row add nothing), then lane 15 of rows 0 and 2 into the rows behind them,
+// then lane 31 into rows 2 and 3.  Six dependent register operations; the same scan with __shfl_up is six round
+// trips through the LDS crossbar (ds_bpermute), a tenth of a microsecond each, and the one-workgroup scan
+// kernels of the binning are chains of exactly such steps.
+__device__ __forceinline__ uint32_t wave_inclusive_sum(uint32_t v) {
+  v += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x111, 0xf, 0xf, false);   // row_shr:1
+  v += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x112, 0xf, 0xf, false);   // row_shr:2
+  v += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x114, 0xf, 0xf, false);   // row_shr:4
+  v += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x118, 0xf, 0xf, false);   // row_shr:8
+  v += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x142, 0xa, 0xf, false);   // row_bcast:15 into rows 1, 3
+  v += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x143, 0xc, 0xf, false);   // row_bcast:31 into rows 2, 3
+  return v;
+}
+
 // The same as a kernel of one workgroup; defined with the binning kernels.
 int launch_totals_final(int blocks, const uint32_t* partials, const uint32_t* status, uint32_t* totals,
                         hipStream_t stream);
