@@ -392,7 +392,7 @@ __global__ void __launch_bounds__(Level<1>::kThreads) write1_kernel(LevelArgs a)
     const int f = wave * kPerWave + q;
     const uint32_t c = lane < kSteps1 ? s_base[lane][f] : 0u;
     const uint32_t inc = gsr::wave_inclusive_sum(c);       // lanes from kSteps1 on hold zeros
-    const uint32_t first = (uint32_t)__shfl((int)piece_pos, q);
+    const uint32_t first = (uint32_t)__builtin_amdgcn_readlane((int)piece_pos, q);
     if (lane < kSteps1) s_base[lane][f] = first + inc - c;
   }
   __syncthreads();

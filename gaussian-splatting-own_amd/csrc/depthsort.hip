@@ -163,7 +163,7 @@ __global__ void __launch_bounds__(kThreads) sort_histogram_kernel(const uint32_t
         for (int it = 0; it < 3; it++) {
           if (rest == 0ull) break;
           const int first = __ffsll((long long)rest) - 1;
-          const uint32_t dv = (uint32_t)__shfl((int)d, first);
+          const uint32_t dv = gsr::lane_value(d, first);
           const unsigned long long same = __ballot(ok && d == dv) & rest;
           if ((int)(threadIdx.x & 63) == first) atomicAdd(&s_h[256 * place + dv], (uint32_t)__popcll(same));
           rest &= ~same;
@@ -172,8 +172,7 @@ __global__ void __launch_bounds__(kThreads) sort_histogram_kernel(const uint32_t
       }
     }
   }
-#pragma unroll
-  for (int o = 32; o > 0; o >>= 1) valid += __shfl_xor(valid, o);
+  valid = gsr::wave_sum(valid);
   if ((threadIdx.x & 63) == 0 && valid) atomicAdd(&s_valid, valid);
   __syncthreads();
   const uint32_t c = s_h[threadIdx.x];
@@ -334,7 +333,7 @@ __global__ void __launch_bounds__(kThreads) sort_pass_kernel(PassArgs a) {
     const unsigned long long all = __ballot(valid[i]);
     if (all != 0ull) {
       const int first = __ffsll((long long)all) - 1;
-      const uint32_t dv = (uint32_t)__shfl((int)digit[i], first);
+      const uint32_t dv = gsr::lane_value(digit[i], first);
       const unsigned long long same = __ballot(valid[i] && digit[i] == dv);
       if (lane == first) atomicAdd(&s_total[dv], (uint32_t)__popcll(same));
       if (valid[i] && digit[i] != dv) atomicAdd(&s_total[digit[i]], 1u);

@@ -114,6 +114,15 @@ __device__ __forceinline__ uint32_t wave_inclusive_sum(uint32_t v) {
   return v;
 }
 
+// Sum over the 64 lanes of a wave, returned to every lane (through a scalar register): the inclusive scan's last lane.
+__device__ __forceinline__ uint32_t wave_sum(uint32_t v) {
+  return (uint32_t)__builtin_amdgcn_readlane((int)wave_inclusive_sum(v), 63);
+}
+// The value lane `from` holds, `from` the same in every lane (a register read, not a shuffle through LDS).
+__device__ __forceinline__ uint32_t lane_value(uint32_t v, int from) {
+  return (uint32_t)__builtin_amdgcn_readlane((int)v, __builtin_amdgcn_readfirstlane(from));
+}
+
 // The same as a kernel of one workgroup; defined with the binning kernels.
 int launch_totals_final(int blocks, const uint32_t* partials, const uint32_t* status, uint32_t* totals,
                         hipStream_t stream);

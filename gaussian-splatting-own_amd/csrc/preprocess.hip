@@ -217,11 +217,7 @@ struct FwdArgs {
   unsigned long long* sort_vals; uint32_t* partials; uint8_t* visible;
 };
 
-__device__ __forceinline__ uint32_t wave_sum_u32(uint32_t v) {
-#pragma unroll
-  for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o);
-  return v;
-}
+__device__ __forceinline__ uint32_t wave_sum_u32(uint32_t v) { return gsr::wave_sum(v); }
 
 // A lane's 64-byte record leaves the kernel through LDS: written as four 16-byte stores per lane the
 // records of a wave would go out as 64 partial writes of 64-byte segments per instruction (one per lane,
