@@ -343,6 +343,63 @@ __device__ __forceinline__ u64 transpose_bits64(u64 x, int lane) {
   return x;
 }
 
+// Levels 2 and 3 count without a sweep over the buckets either.  Their entries cover a run of the parent's 16 buckets,
+// a 16-bit mask; a lane packs the masks of four entries (64 entries apart) into one 64-bit word, and the transpose
+// of the wave's 64 words leaves in lane 16 c + f the word "which entries of group c cover bucket f": the sixteen
+// ballots of the sweep for four groups of 64 entries at once, from a dozen lane exchanges.  Their popcounts are the
+// counts.  (The writing sweeps keep the ballots per bucket: they need every entry's rank bucket by bucket, and
+// their stores are what they wait for.)
+template <int LEVEL>
+__global__ void __launch_bounds__(Level<LEVEL>::kThreads) count_kernel(LevelArgs a) {
+  static_assert(LEVEL == 2 || LEVEL == 3, "level 1 counts with a difference array");
+  constexpr uint32_t L = Level<LEVEL>::kPiece;
+  constexpr int T = Level<LEVEL>::kThreads, kWaves = T / 64;
+  static_assert(kSuper == 16 && L % (256 * kWaves) == 0, "four groups of 64 entries per wave and round");
+  __shared__ uint32_t s_cnt[kSuper];
+  const uint32_t parents = LEVEL == 2 ? (uint32_t)a.g.supercells() : (uint32_t)a.g.cells();
+  if (blockIdx.x >= a.piece_first[parents]) return;
+  const uint4 d = a.desc[blockIdx.x];
+  const uint32_t pf0 = a.piece_first[d.x], np = a.piece_first[d.x + 1] - pf0;
+  const uint32_t parent = d.x, start = d.y, len = d.z, slot0 = pf0 * kSuper + d.w;
+  const uint32_t cy = (parent / (uint32_t)a.g.sx) * kSuper;                  // level 2: the supercell's first tile row
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  if (threadIdx.x < kSuper) s_cnt[threadIdx.x] = 0u;
+  __syncthreads();
+  uint32_t mine = 0u;                  // lane 16 c + f: entries of the wave's groups c that cover bucket f
+  for (uint32_t base = (uint32_t)wave * 256u; base < len; base += (uint32_t)kWaves * 256u) {
+    u64 en[4];
+#pragma unroll
+    for (int c = 0; c < 4; c++) {
+      const uint32_t i = base + 64u * c + (uint32_t)lane;
+      en[c] = i < len ? a.in[start + i] : ~0ull;
+    }
+    u64 word = 0ull;
+#pragma unroll
+    for (int c = 0; c < 4; c++) {
+      const uint32_t i = base + 64u * c + (uint32_t)lane;
+      uint32_t lo, hi;
+      if (LEVEL == 2) {
+        uint32_t x0, x1, y0, y1;
+        a.pk.rect(en[c], x0, x1, y0, y1);
+        lo = max(y0, cy) - cy;
+        hi = min(y1, cy + kSuper - 1u) - cy;
+      } else {
+        const uint32_t lb = (uint32_t)(en[c] >> 32);
+        lo = lb & 15u;
+        hi = (lb >> 4) & 15u;
+      }
+      const uint32_t mask = i < len ? ((2u << (hi - lo)) - 1u) << lo : 0u;
+      word |= (u64)(mask & 0xffffu) << (16 * c);
+    }
+    mine += (uint32_t)__popcll(transpose_bits64(word, lane));
+  }
+  mine += (uint32_t)__shfl_xor((int)mine, 16);
+  mine += (uint32_t)__shfl_xor((int)mine, 32);
+  if (lane < kSuper && mine) atomicAdd(&s_cnt[lane], mine);
+  __syncthreads();
+  if (threadIdx.x < kSuper) a.counts[slot0 + threadIdx.x * np] = s_cnt[threadIdx.x];
+}
+
 constexpr int kSteps1 = (int)(kPiece1 / 64);                       // steps of 64 entries per piece
 static_assert(kPiece1 == 2 * Level<1>::kThreads && kSteps1 <= 64, "write1_kernel: two entries per thread, steps scanned by one wave");
 
@@ -796,7 +853,7 @@ extern "C" int gsr_bin_lists(int P, uint32_t V, uint32_t N, uint32_t E1, uint32_
   a.desc = (const uint4*)(base + L.desc2);
   a.counts = (uint32_t*)(base + L.counts2);
   a.out64 = (u64*)(base + L.entries2);
-  hipLaunchKernelGGL((partition_kernel<2, false>), dim3(L.max_pieces2), dim3(Level<2>::kThreads), 0, st, a);
+  hipLaunchKernelGGL(count_kernel<2>, dim3(L.max_pieces2), dim3(Level<2>::kThreads), 0, st, a);
   hipLaunchKernelGGL(scan2_kernel, dim3(1), dim3(kScanBlock), 0, st, g, a.piece_first, a.counts,
                      (uint32_t*)(base + L.list_start3), (uint32_t*)(base + L.list_len3),
                      (uint32_t*)(base + L.piece_first3), (uint4*)(base + L.desc3));
@@ -811,7 +868,7 @@ extern "C" int gsr_bin_lists(int P, uint32_t V, uint32_t N, uint32_t E1, uint32_
   a.counts = (uint32_t*)(base + L.counts3);
   a.out64 = nullptr;
   a.out32 = point_list;
-  hipLaunchKernelGGL((partition_kernel<3, false>), dim3(L.max_pieces3), dim3(Level<3>::kThreads), 0, st, a);
+  hipLaunchKernelGGL(count_kernel<3>, dim3(L.max_pieces3), dim3(Level<3>::kThreads), 0, st, a);
   hipLaunchKernelGGL(scan3_kernel, dim3(1), dim3(kScanBlock), 0, st, g, a.piece_first, a.counts,
                      ranges);
   hipLaunchKernelGGL((partition_kernel<3, true>), dim3(L.max_pieces3), dim3(Level<3>::kThreads), 0, st, a);
