@@ -62,43 +62,6 @@ inline Pack make_pack(int P, int tiles_x, int tiles_y) {
   return k;
 }
 
-// One workgroup of THREADS threads sums `blocks` partial records of four counters (partials[4 * b + k]) into
-// totals[0..3] and copies the caller's status word (null = 0) to totals[4].  Returns totals[t] to thread t < 5
-// (0 to the others).  s_part: THREADS / 64 rows of LDS.
-template <int THREADS>
-__device__ __forceinline__ uint32_t sum_totals(int blocks, const uint32_t* __restrict__ partials,
-                                               const uint32_t* __restrict__ status, uint32_t* __restrict__ totals,
-                                               uint32_t (*s_part)[4]) {
-  uint32_t acc[4] = {0u, 0u, 0u, 0u};
-  // four independent 16-byte loads per thread and round
-  for (int b0 = threadIdx.x; b0 < blocks; b0 += 4 * THREADS) {
-    uint4 p[4];
-#pragma unroll
-    for (int k = 0; k < 4; k++) {
-      const int b = b0 + k * THREADS;
-      p[k] = b < blocks ? reinterpret_cast<const uint4*>(partials)[b] : make_uint4(0u, 0u, 0u, 0u);
-    }
-#pragma unroll
-    for (int k = 0; k < 4; k++) { acc[0] += p[k].x; acc[1] += p[k].y; acc[2] += p[k].z; acc[3] += p[k].w; }
-  }
-  const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
-#pragma unroll
-  for (int k = 0; k < 4; k++) {
-#pragma unroll
-    for (int o = 32; o > 0; o >>= 1) acc[k] += __shfl_xor(acc[k], o);
-    if (lane == 0) s_part[wave][k] = acc[k];
-  }
-  __syncthreads();
-  uint32_t mine = 0u;
-  if (threadIdx.x < 4) {
-#pragma unroll
-    for (int w = 0; w < THREADS / 64; w++) mine += s_part[w][threadIdx.x];
-    totals[threadIdx.x] = mine;
-  }
-  if (threadIdx.x == 4) totals[4] = mine = status ? *status : 0u;
-  return mine;
-}
-
 // Inclusive prefix sum over the 64 lanes of a wave with DPP alone: row_shr 1, 2, 4, 8 inside the rows of 16 lanes
 // (lanes whose source lies outside their row add nothing), then lane 15 of rows 0 and 2 into the rows behind them,
 // then lane 31 into rows 2 and 3.  Six dependent register operations; the same scan with __shfl_up is six round
@@ -121,6 +84,42 @@ __device__ __forceinline__ uint32_t wave_sum(uint32_t v) {
 // The value lane `from` holds, `from` the same in every lane (a register read, not a shuffle through LDS).
 __device__ __forceinline__ uint32_t lane_value(uint32_t v, int from) {
   return (uint32_t)__builtin_amdgcn_readlane((int)v, __builtin_amdgcn_readfirstlane(from));
+}
+
+// One workgroup of THREADS threads sums `blocks` partial records of four counters (partials[4 * b + k]) into
+// totals[0..3] and copies the caller's status word (null = 0) to totals[4].  Returns totals[t] to thread t < 5
+// (0 to the others).  s_part: THREADS / 64 rows of LDS.
+template <int THREADS>
+__device__ __forceinline__ uint32_t sum_totals(int blocks, const uint32_t* __restrict__ partials,
+                                               const uint32_t* __restrict__ status, uint32_t* __restrict__ totals,
+                                               uint32_t (*s_part)[4]) {
+  uint32_t acc[4] = {0u, 0u, 0u, 0u};
+  // four independent 16-byte loads per thread and round
+  for (int b0 = threadIdx.x; b0 < blocks; b0 += 4 * THREADS) {
+    uint4 p[4];
+#pragma unroll
+    for (int k = 0; k < 4; k++) {
+      const int b = b0 + k * THREADS;
+      p[k] = b < blocks ? reinterpret_cast<const uint4*>(partials)[b] : make_uint4(0u, 0u, 0u, 0u);
+    }
+#pragma unroll
+    for (int k = 0; k < 4; k++) { acc[0] += p[k].x; acc[1] += p[k].y; acc[2] += p[k].z; acc[3] += p[k].w; }
+  }
+  const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+#pragma unroll
+  for (int k = 0; k < 4; k++) {
+    acc[k] = wave_sum(acc[k]);
+    if (lane == 0) s_part[wave][k] = acc[k];
+  }
+  __syncthreads();
+  uint32_t mine = 0u;
+  if (threadIdx.x < 4) {
+#pragma unroll
+    for (int w = 0; w < THREADS / 64; w++) mine += s_part[w][threadIdx.x];
+    totals[threadIdx.x] = mine;
+  }
+  if (threadIdx.x == 4) totals[4] = mine = status ? *status : 0u;
+  return mine;
 }
 
 // The same as a kernel of one workgroup; defined with the binning kernels.
