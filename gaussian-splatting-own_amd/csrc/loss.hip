@@ -158,7 +158,8 @@ __global__ void __launch_bounds__(256, GSR_LOSS_FWD_PER_CU) loss_fwd_kernel(int 
     const float* const xc = img + c * plane;
     const float* const yc = gt + c * plane;
     // (the 336 tasks are a round of 256 and a round of 80, which leaves two waves idle; a quarter of the tasks to every
-    // wave, 64 + 20, keeps all four busy and is slower, 57.5 -> 60.3 us at 1080p: four partly filled rounds issue more)
+    // wave, 64 + 20, keeps all four busy and is slower, 57.5 -> 60.3 us at 1080p: four partly filled rounds issue more;
+    // letting the second round fall to waves 2 and 3 on every other tile, so that no SIMD always has it: no change)
     for (int k = threadIdx.x; k < kHTasks; k += 256) {
       const int r = k / (kTX / kOut), q = (k % (kTX / kOut)) * kOut;
       float a[kNeed], b[kNeed], o[4][kOut];
