@@ -125,7 +125,9 @@ def _arena_worker(rank, world, port, q):
         assert all_reduce_gradients(separate, method=method) == scale
         for k in params:
             assert torch.equal(separate[k].grad, params[k].grad), (method, k)
-    q.put((rank, scale, {k: (p.grad * scale).clone() for k, p in params.items()}))
+    # as numpy arrays: a tensor in a queue travels as a shared-memory handle that the receiver must fetch from this
+    # process while it is still alive, which a worker that finishes first does not wait for
+    q.put((rank, scale, {k: (p.grad * scale).numpy().copy() for k, p in params.items()}))
     # losses already normalised over all ranks' views: the sum is the gradient, nothing left to scale
     assert all_reduce_gradients({}, average=False) == 1.0 and all_reduce_gradients({}) == 0.5
     dist.barrier()
@@ -158,4 +160,4 @@ def test_gradient_arena_all_reduce_gives_the_mean_gradient():
     for rank, scale, grads in results:
         assert scale == 0.5
         for k in want:
-            assert torch.allclose(grads[k], want[k], atol=1e-6), (rank, k)
+            assert torch.allclose(torch.from_numpy(grads[k]), want[k], atol=1e-6), (rank, k)
