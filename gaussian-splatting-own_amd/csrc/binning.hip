@@ -70,11 +70,12 @@ using gsr::Pack;
 // totals: N = tile instances, E1 = supercell entries, E2 = cell entries, V = visible Gaussians
 // ---------------------------------------------------------------------------
 // Sums the per-block partial records the preprocess geometry kernel leaves behind.
-// totals[4] = the caller's status word as it stands (0 without one): it rides to the host with the sizes.
+// totals[4] = the caller's status word as it stands (0 without one): it rides to the host with the sizes;
+// totals[5] = 1 if the frame has more tile instances than the 32-bit sizes hold (gsr::kMaxInstances).
 __global__ void __launch_bounds__(kScanBlock) totals_final_kernel(int blocks, const uint32_t* __restrict__ partials,
                                                                   const uint32_t* __restrict__ status,
                                                                   uint32_t* __restrict__ totals) {
-  __shared__ uint32_t s_part[kScanBlock / 64][4];
+  __shared__ uint32_t s_part[kScanBlock / 64][5];
   gsr::sum_totals<kScanBlock>(blocks, partials, status, totals, s_part);
 }
 

@@ -106,9 +106,9 @@ __device__ __forceinline__ uint32_t wave_incl_scan(uint32_t v) { return gsr::wav
 // costs neither a kernel of its own, nor a copy command between the preprocess and the sort, nor an event.
 template <int THREADS>
 __device__ __forceinline__ void send_list_sizes(const gsr::SortMirror& m) {
-  __shared__ uint32_t s_part[THREADS / 64][4];
+  __shared__ uint32_t s_part[THREADS / 64][5];
   const uint32_t mine = gsr::sum_totals<THREADS>(m.blocks, m.partials, m.status, m.totals, s_part);
-  if (threadIdx.x < 7) m.dst[threadIdx.x] = mine;          // words 5 and 6 are spare: 0
+  if (threadIdx.x < 7) m.dst[threadIdx.x] = mine;          // word 5: too many instances; word 6 is spare: 0
   __threadfence_system();
   __syncthreads();
   if (threadIdx.x == 0) {

@@ -172,6 +172,9 @@ extern "C" int gsr_forward(const GsrForwardArgs* a, gsr_resize_fn resize, void* 
       e = hipEventSynchronize((hipEvent_t)a->event);
       if (e != hipSuccess) return hip_fail("waiting for the list sizes", e);
     }
+    if (a->h_totals[5])
+      return gsr::fail(GSR_E_TOO_LARGE, "forward: the frame has more than %.0f tile instances (%d Gaussians on %dx%d pixels): "
+                       "the lists' sizes are 32-bit, as the published module's are; nothing was rendered", (double)gsr::kMaxInstances, P, W, H);
     N = a->h_totals[0]; E1 = a->h_totals[1]; E2 = a->h_totals[2]; V = a->h_totals[3];
     out->carried_status = a->h_totals[4];
     if (out->carried_status)

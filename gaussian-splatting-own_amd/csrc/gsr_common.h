@@ -81,19 +81,38 @@ __device__ __forceinline__ uint32_t wave_inclusive_sum(uint32_t v) {
 __device__ __forceinline__ uint32_t wave_sum(uint32_t v) {
   return (uint32_t)__builtin_amdgcn_readlane((int)wave_inclusive_sum(v), 63);
 }
+// The same for floats (an invalid source adds +0).
+__device__ __forceinline__ float wave_sum_f32(float v) {
+  v += __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v), 0x111, 0xf, 0xf, false));
+  v += __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v), 0x112, 0xf, 0xf, false));
+  v += __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v), 0x114, 0xf, 0xf, false));
+  v += __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v), 0x118, 0xf, 0xf, false));
+  v += __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v), 0x142, 0xa, 0xf, false));
+  v += __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v), 0x143, 0xc, 0xf, false));
+  return __int_as_float(__builtin_amdgcn_readlane(__float_as_int(v), 63));
+}
 // The value lane `from` holds, `from` the same in every lane (a register read, not a shuffle through LDS).
 __device__ __forceinline__ uint32_t lane_value(uint32_t v, int from) {
   return (uint32_t)__builtin_amdgcn_readlane((int)v, __builtin_amdgcn_readfirstlane(from));
 }
 
+// The list sizes are 32-bit sums (as the published module's are: its instance count is an int), so a frame may hold
+// at most kMaxInstances tile instances.  More would wrap the sums and let the list builder write past the lists, so
+// the summing workgroup also adds the instance counts up as floats (exact to a few thousand at this size, hence
+// the margin below 2^31) and raises a flag that stops the forward before any list is sized.
+// (A block's own partial sum cannot wrap: 256 Gaussians on at most 4080 x 4080 tiles, the largest image accepted.)
+constexpr float kMaxInstances = (float)GSR_MAX_INSTANCES;   // 2^31 - 2^22
+
 // One workgroup of THREADS threads sums `blocks` partial records of four counters (partials[4 * b + k]) into
-// totals[0..3] and copies the caller's status word (null = 0) to totals[4].  Returns totals[t] to thread t < 5
-// (0 to the others).  s_part: THREADS / 64 rows of LDS.
+// totals[0..3], copies the caller's status word (null = 0) to totals[4] and sets totals[5] to 1 if the first
+// counter's true sum is kMaxInstances or more (then totals[0..3] mean nothing).  Returns totals[t] to thread
+// t < 6 (0 to the others).  s_part: THREADS / 64 rows of LDS.
 template <int THREADS>
 __device__ __forceinline__ uint32_t sum_totals(int blocks, const uint32_t* __restrict__ partials,
                                                const uint32_t* __restrict__ status, uint32_t* __restrict__ totals,
-                                               uint32_t (*s_part)[4]) {
+                                               uint32_t (*s_part)[5]) {
   uint32_t acc[4] = {0u, 0u, 0u, 0u};
+  float instances = 0.f;
   // four independent 16-byte loads per thread and round
   for (int b0 = threadIdx.x; b0 < blocks; b0 += 4 * THREADS) {
     uint4 p[4];
@@ -103,7 +122,10 @@ __device__ __forceinline__ uint32_t sum_totals(int blocks, const uint32_t* __res
       p[k] = b < blocks ? reinterpret_cast<const uint4*>(partials)[b] : make_uint4(0u, 0u, 0u, 0u);
     }
 #pragma unroll
-    for (int k = 0; k < 4; k++) { acc[0] += p[k].x; acc[1] += p[k].y; acc[2] += p[k].z; acc[3] += p[k].w; }
+    for (int k = 0; k < 4; k++) {
+      acc[0] += p[k].x; acc[1] += p[k].y; acc[2] += p[k].z; acc[3] += p[k].w;
+      instances += (float)p[k].x;
+    }
   }
   const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
 #pragma unroll
@@ -111,6 +133,8 @@ __device__ __forceinline__ uint32_t sum_totals(int blocks, const uint32_t* __res
     acc[k] = wave_sum(acc[k]);
     if (lane == 0) s_part[wave][k] = acc[k];
   }
+  instances = wave_sum_f32(instances);
+  if (lane == 0) s_part[wave][4] = __float_as_uint(instances);
   __syncthreads();
   uint32_t mine = 0u;
   if (threadIdx.x < 4) {
@@ -119,6 +143,12 @@ __device__ __forceinline__ uint32_t sum_totals(int blocks, const uint32_t* __res
     totals[threadIdx.x] = mine;
   }
   if (threadIdx.x == 4) totals[4] = mine = status ? *status : 0u;
+  if (threadIdx.x == 5) {
+    float t = 0.f;
+#pragma unroll
+    for (int w = 0; w < THREADS / 64; w++) t += __uint_as_float(s_part[w][4]);
+    totals[5] = mine = t >= kMaxInstances ? 1u : 0u;
+  }
   return mine;
 }
 

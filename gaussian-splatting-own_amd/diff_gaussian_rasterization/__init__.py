@@ -87,6 +87,8 @@ class _ForwardOut(C.Structure):
 _RESIZE_FN = C.CFUNCTYPE(C.c_void_p, C.c_void_p, C.c_size_t)
 _HOOK_FN = C.CFUNCTYPE(None, C.c_void_p)
 GSR_E_EARLIER = -6
+GSR_E_TOO_LARGE = -5
+MAX_INSTANCES = 2143289344      # GSR_MAX_INSTANCES in gsr.h
 
 
 def _load():
@@ -283,7 +285,7 @@ def _stream():
 # render on one device (each on its own stream) never share a landing buffer, a side stream or a
 # status word.  The library itself keeps no state.
 _local = threading.local()
-TOTALS_HEAD = 8            # words the host reads back: N, E1, E2, V, status, 3 spare (gsr_totals_words)
+TOTALS_HEAD = 8            # words the host reads back: N, E1, E2, V, status, too many instances, 2 spare (gsr_totals_words)
 STATUS_SORT, STATUS_TOTALS = 1, 2
 
 
@@ -733,7 +735,11 @@ def rasterize_forward(s: GaussianRasterizationSettings, means3D, opacities, shs=
             # a synchronising check, as the replaced module synchronises after every stage in this mode
             _run("bin_sort_status", _lib.gsr_bin_sort_status, P, _ptr(sort_scratch), nb, stream)
         copied.synchronize()
-        N, E1, E2, V, carried = (int(v) & 0xFFFFFFFF for v in host.tolist()[:5])
+        N, E1, E2, V, carried, too_many = (int(v) & 0xFFFFFFFF for v in host.tolist()[:6])
+        if too_many:
+            # the sizes above have wrapped; nothing has been sized by them yet (gsr_forward refuses the same way)
+            raise RuntimeError(f"libgsr_hip forward failed ({GSR_E_TOO_LARGE}): more than {MAX_INSTANCES} tile instances in "
+                               f"one frame ({P} Gaussians on {W}x{H} pixels): the lists' sizes are 32-bit")
         if carried:
             # an earlier forward of this thread refused to build its lists; this one has not been hurt
             # (it is abandoned here, before its own lists are built)

@@ -53,7 +53,12 @@ extern "C" {
 #define GSR_E_LAUNCH (-2)    /* HIP reported an error on launch / enqueue                    */
 #define GSR_E_SCRATCH (-3)   /* scratch buffer too small or misaligned                       */
 #define GSR_E_SORT (-4)      /* the depth sort gave up waiting (see gsr_bin_sort_status)     */
-#define GSR_E_TOO_LARGE (-5) /* the input exceeds a fixed capacity (gsr_bin_sort_static)      */
+#define GSR_E_TOO_LARGE (-5) /* the input exceeds a fixed capacity (gsr_bin_sort_static,
+                                GSR_MAX_INSTANCES)                                             */
+/* Tile instances (pairs of a Gaussian and a tile it is binned into) one frame may
+ * hold: 2^31 - 2^22.  A million Gaussians that each cover a whole 1080p frame
+ * would be four times that. */
+#define GSR_MAX_INSTANCES 2143289344u
 #define GSR_E_EARLIER (-6)   /* gsr_forward: the status word carries an earlier call's failure */
 
 /* Bits of the caller's device-side status word (see gsr_bin_lists). */
@@ -112,7 +117,11 @@ const char* gsr_last_error(void);
  * scratch) and is 16-byte aligned.
  * status (may be NULL): the caller's device-side status word, see gsr_bin_lists;
  * its value at this point is copied to totals[4], so that it reaches the host with
- * the list sizes at no extra cost (totals[5..7] are reserved).
+ * the list sizes at no extra cost.
+ * totals[5] = 1 if the frame holds GSR_MAX_INSTANCES tile instances or more: the
+ * sizes are 32-bit sums (the published module's instance count is an int) and
+ * have wrapped or are about to; the caller must not size lists by them
+ * (gsr_forward stops with GSR_E_TOO_LARGE).  totals[6..7] are reserved.
  *
  * visible (P) uint8, optional (may be NULL): radii > 0, the `visibility_filter`
  * render() returns (gaussian_renderer/__init__.py:99).
@@ -293,7 +302,9 @@ int gsr_blend_fwd(int W, int H, const uint32_t* ranges, const uint32_t* point_li
  * takes 10.
  * If totals[4] shows that an earlier call on the same status word built no
  * lists, the call stops before its own lists with GSR_E_EARLIER
- * (out->carried_status holds the bits; clearing the word is the caller's). */
+ * (out->carried_status holds the bits; clearing the word is the caller's).
+ * A frame of GSR_MAX_INSTANCES tile instances or more stops at the same point
+ * with GSR_E_TOO_LARGE: nothing is rendered, later calls are not affected. */
 typedef void* (*gsr_resize_fn)(void* ctx, size_t bytes);
 typedef struct GsrForwardArgs {
   int P, D, M, raw;

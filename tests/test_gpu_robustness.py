@@ -485,3 +485,43 @@ def test_two_prepared_forwards_alive_at_once_backward_in_reverse_order():
             assert torch.equal(grads[k][name], v), (k, name)
             assert torch.equal(again[k][name], v), (k, name)
         assert float(alone[k]["means3D"].abs().max()) > 0.0
+
+
+@pytest.mark.parametrize("P", [300_000, 600_000])
+def test_a_frame_with_more_instances_than_32_bits_hold_is_refused(P):
+    """The list sizes are 32-bit sums, as the replaced module's instance count is an int.  Gaussians that have grown
+    until each covers the whole 1080p frame (8160 tiles) bring 2.4e9 instances at 300k, and 4.9e9 at 600k, where the
+    sum has wrapped to a harmless-looking 0.6e9: sizing the lists by it would let the list builder write past them.
+    The forward stops before any list is sized, on the single call (both read-backs) and on the stage calls, and
+    the next frame is not affected."""
+    import diff_gaussian_rasterization as dgr
+    cloud, cam, bg, _ = make_scene(P, 1920, 1080, sh_degree=0, seed=3, coeffs=1)
+    s = _gpu_settings(cam, bg, 0, 1.0)
+    c = cloud.to("cuda")
+    before = _forward(dgr, s, c, single_call=True)
+    huge = torch.full_like(c.scaling, 60.0)
+    opaque = torch.full_like(c.opacity, 0.9)
+
+    def grown(**kw):
+        return dgr.rasterize_forward(s, c.xyz, opaque, shs=c.features, scales=huge, rotations=c.rotation, **kw)
+
+    with pytest.raises(RuntimeError, match="tile instances"):
+        grown(single_call=True)
+    slot = dgr._per_device(torch.device("cuda", torch.cuda.current_device()))
+    kept = slot["pinned"]
+    slot["pinned"] = torch.full((dgr.TOTALS_HEAD,), -1, dtype=torch.int32)      # ordinary host memory: the other read-back
+    try:
+        with pytest.raises(RuntimeError, match="tile instances"):
+            grown(single_call=True)
+    finally:
+        slot["pinned"] = kept
+    with pytest.raises(RuntimeError, match="tile instances"):
+        grown(single_call=False)
+    torch.cuda.synchronize()
+    for single in (True, False):
+        after = _forward(dgr, s, c, single_call=single)
+        assert after.num_rendered == before.num_rendered > 0
+        assert torch.equal(after.point_list, before.point_list) and torch.equal(after.color, before.color)
+    # just how many there were: every Gaussian in front of the near plane, on every tile
+    z = (torch.cat((cloud.xyz, torch.ones(P, 1)), dim=1) @ cam.world_view_transform)[:, 2]
+    assert int((z > 0.2).sum()) * 8160 >= dgr.MAX_INSTANCES
