@@ -525,3 +525,47 @@ def test_a_frame_with_more_instances_than_32_bits_hold_is_refused(P):
     # just how many there were: every Gaussian in front of the near plane, on every tile
     z = (torch.cat((cloud.xyz, torch.ones(P, 1)), dim=1) @ cam.world_view_transform)[:, 2]
     assert int((z > 0.2).sum()) * 8160 >= dgr.MAX_INSTANCES
+
+
+def test_parameters_that_have_diverged_do_no_harm_beyond_their_own_pixels(oracle32):
+    """A training run that diverges hands the rasterizer NaN, infinities and 1e38 in any parameter.  Such a Gaussian
+    is culled or binned exactly as the oracle does it (a NaN covariance gives the largest radius there is: the
+    whole frame), the lists stay bit-exact, every kernel ends, and the next clean frame is what it was."""
+    import diff_gaussian_rasterization as dgr
+    from scenes import cloud_numpy, oracle_settings
+    P = 3000
+    cloud, cam, bg, _ = make_scene(P, 200, 150, sh_degree=1, seed=5, coeffs=4)
+    s = _gpu_settings(cam, bg, 1, 1.0)
+    clean = _forward(dgr, s, cloud.to("cuda"), single_call=True)
+    rng = np.random.default_rng(0)
+    bad = [np.nan, np.inf, -np.inf, 1e38, -1e38, 1e-45]
+    for t in (cloud.xyz, cloud.scaling, cloud.rotation, cloud.opacity, cloud.features):
+        a = t.numpy()                                           # shares the tensor's memory
+        for j, i in enumerate(rng.choice(P, 60, replace=False)):
+            a[i].reshape(-1)[rng.integers(a[i].size)] = bad[j % len(bad)]
+    ref = oracle32.forward(oracle_settings(cam, bg, 1, 1.0), **cloud_numpy(cloud))
+    assert ref["pre"]["radii"].max() == 2147483647 and np.isnan(ref["fwd"]["color"]).any()
+    c = cloud.to("cuda")
+    for single in (True, False):
+        st = _forward(dgr, s, c, single_call=single, reference_lists=True, keep_tile_ids=True)
+        torch.cuda.synchronize()
+        assert np.array_equal(st.radii.cpu().numpy(), ref["pre"]["radii"])
+        assert st.num_rendered == ref["bin"]["n_dup"]
+        assert np.array_equal(st.point_list.cpu().numpy().view(np.uint32), ref["bin"]["point_list"])
+        assert np.array_equal(st.ranges.cpu().numpy().view(np.uint32), ref["bin"]["ranges"])
+        # (the pixels themselves are not compared: the oracle, like the published kernel, blends a Gaussian whose
+        # exponent is NaN, "power > 0" being false for it, and every pixel of this frame ends up NaN there; the
+        # blend kernels ask "power <= 0" and leave such a Gaussian out)
+    # the short lists, forward and backward: everything ends, the gradients of the untouched Gaussians are numbers
+    dL = torch.randn((3, 150, 200), generator=torch.Generator().manual_seed(1)).cuda()
+    for single in (True, False):
+        st = _forward(dgr, s, c, single_call=single, prepare_backward=single)
+        g = dgr.rasterize_backward(s, st, dL, c.xyz, shs=c.features, scales=c.scaling, rotations=c.rotation)
+        torch.cuda.synchronize()
+        assert all(v.shape[0] == P for v in g.values() if v is not None)
+        # a Gaussian none of whose parameters was touched and that no poisoned one shares a pixel with cannot be told
+        # apart here (the whole-frame ones share every pixel), so only this: the clean rows of the means' gradient
+        # are not all NaN, i.e. the backward did its work around the poison
+        assert bool(torch.isfinite(g["means3D"]).any())
+    again = _forward(dgr, s, make_scene(P, 200, 150, sh_degree=1, seed=5, coeffs=4)[0].to("cuda"), single_call=True)
+    assert torch.equal(again.color, clean.color) and torch.equal(again.point_list, clean.point_list)
