@@ -51,6 +51,10 @@ CASES = {
     "uhd_3840x2160": (20_000, 3840, 2160, 1, 4, (0.0, 0.0, 0.0), 1.0, {}),
     "one_hot_tile": (12_000, 96, 64, 0, 1, (0.0, 0.0, 0.0), 1.0, dict(skew_fraction=1.0, distance=30.0)),
     "single_tile_image": (500, 16, 16, 0, 1, (0.3, 0.3, 0.3), 1.0, {}),
+    # grids far from 1080p's: 510 supercells (30 x 17, partial at both edges), one row of 64 supercells, one column of 36
+    "uhd8k_7680x4320": (8_000, 7680, 4320, 0, 1, (0.0, 0.0, 0.0), 1.0, {}),
+    "panorama_16384x64": (20_000, 16384, 64, 0, 1, (0.0, 0.0, 0.0), 1.0, dict(scale_mult=2.0)),
+    "tower_48x9000": (20_000, 48, 9000, 1, 4, (0.5, 0.5, 0.5), 1.0, {}),
 }
 
 
@@ -186,7 +190,7 @@ def _rel_err(got, ref):
     return np.abs(got - ref).max() / scale
 
 
-BACKWARD_CASES = list(CASES)
+BACKWARD_CASES = [c for c in CASES if c != "uhd8k_7680x4320"]    # (it passes; the oracle's backward over 33M pixels takes 45 s)
 
 
 def _backward_errors(orc, s_cpu, cn, ref, dL, g, ds):
