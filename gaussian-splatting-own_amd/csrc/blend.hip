@@ -15,6 +15,7 @@
 #include <atomic>
 #include <cstdlib>
 #include <string>
+#include <type_traits>
 
 #include "gsr_common.h"
 
@@ -608,11 +609,13 @@ __global__ void __launch_bounds__(128) blend_bwd_pair_kernel(int W, int H, const
   if (in1) { r1 = dL_dpix[pix1]; g1 = dL_dpix[plane + pix1]; b1 = dL_dpix[2 * plane + pix1]; }
   const float bgr = bg[0], bgg = bg[1], bgb = bg[2];
   const float Tf_bg0 = Tf0 * (bgr * r0 + bgg * g0 + bgb * b0), Tf_bg1 = Tf1 * (bgr * r1 + bgg * g1 + bgb * b1);
-  int wl = max(last0, last1);
+  int wl = max(last0, last1), wf = min(last0, last1);
 #pragma unroll
-  for (int o = 32; o > 0; o >>= 1) wl = max(wl, __shfl_xor(wl, o));
+  for (int o = 32; o > 0; o >>= 1) { wl = max(wl, __shfl_xor(wl, o)); wf = min(wf, __shfl_xor(wf, o)); }
   if (lane == 0) s_last[wave] = wl;
   __syncthreads();
+  // entries in front of this position are blended by every pixel of the half tile (0 where the tile leaves the image)
+  const int wave_first_end = __builtin_amdgcn_readfirstlane(wf);
   // the deepest position this item visits (exclusive), for the half tile and for the tile
   const int wave_last = min(__builtin_amdgcn_readfirstlane(wl), hi);
   const int tile_last = min(max(s_last[0], s_last[1]), hi);
@@ -664,56 +667,69 @@ __global__ void __launch_bounds__(128) blend_bwd_pair_kernel(int W, int H, const
     __syncthreads();
 
     if (b * kPairBatch >= wave_last) continue;   // nothing this deep for this half tile
+    // one (wave, splat) turn; kCheckEnds = false where every pixel of the half tile is known to go deeper than the
+    // splat (then the two comparisons with the pixels' own ends are left out)
+    auto turn = [&](const int j, auto check_ends) {
+      constexpr bool kCheckEnds = decltype(check_ends)::value;
+      const int pos = b * kPairBatch + j;
+      const float4 geo = s_splat.geo[j], col = s_splat.col[j];
+      // the same subtractions and the same exponent as the forward's, per pixel
+      const float dxa = geo.x - x0f, dxb = geo.x - x1f, dy = geo.y - yf;
+      const float row = gauss_exponent_row(col.x, dy), lb_dy = geo.w * dy;
+      const float pa = gauss_exponent(geo.z, lb_dy, row, dxa), pb = gauss_exponent(geo.z, lb_dy, row, dxb);
+      float oGa = col.y * __builtin_amdgcn_exp2f(pa), oGb = col.y * __builtin_amdgcn_exp2f(pb);
+      const bool hita = (pa <= 0.0f) & (oGa >= GSR_ALPHA_MIN) & (!kCheckEnds || pos < last0);
+      const bool hitb = (pb <= 0.0f) & (oGb >= GSR_ALPHA_MIN) & (!kCheckEnds || pos < last1);
+      if (__ballot(hita | hitb) == 0ull) return;
+      oGa = hita ? oGa : 0.0f;
+      oGb = hitb ? oGb : 0.0f;
+      const float alphaa = __builtin_amdgcn_fmed3f(oGa, 0.0f, GSR_ALPHA_MAX), alphab = __builtin_amdgcn_fmed3f(oGb, 0.0f, GSR_ALPHA_MAX);
+      const float inva = __builtin_amdgcn_rcpf(1.0f - alphaa), invb = __builtin_amdgcn_rcpf(1.0f - alphab);
+      T0 *= inva;
+      T1 *= invb;
+      const float2 bi = s_splat.tail[j];
+      const float da = fmaf(bi.x, b0, fmaf(col.w, g0, col.z * r0)) - behind0;
+      const float db = fmaf(bi.x, b1, fmaf(col.w, g1, col.z * r1)) - behind1;
+      const float ua = fmaf(da, T0, -(Tf_bg0 * inva)) * oGa, ub = fmaf(db, T1, -(Tf_bg1 * invb)) * oGb;
+      behind0 = fmaf(alphaa, da, behind0);
+      behind1 = fmaf(alphab, db, behind1);
+      const float wa = alphaa * T0, wb = alphab * T1;
+      // the pair's nine contributions; dy is common to the two pixels
+      const float u = ua + ub;
+      const float uxa = ua * dxa, uxb = ub * dxb;
+      const float ux = uxa + uxb;
+      const float uxx = fmaf(uxb, dxb, uxa * dxa);
+      const float uy = u * dy;
+      store_rows_addtid(red_base, u, ux, uy, uxx, ux * dy, uy * dy, fmaf(wb, r1, wa * r0), fmaf(wb, g1, wa * g0));
+      const float4 a0 = *red_lo, a1 = *red_hi;
+      float v = ((a0.x + a0.y) + (a0.z + a0.w)) + ((a1.x + a1.y) + (a1.z + a1.w));
+      float v8 = fmaf(wb, b1, wa * b0);
+      v = dpp_add<0xB1>(v); v = dpp_add<0x4E>(v); v = dpp_add<0x141>(v);
+      // (the sum is wanted by a few lanes only, and left to itself the compiler moves the last addition behind
+      // their branch, where it cannot be part of the cross-lane instruction any more: three instructions for one)
+      asm volatile("" : "+v"(v));
+      v8 = sum_into_last_row(v8);
+      // the row's address as a scalar (every lane holds the same index), the lane's word as a constant offset
+      float* const grad_row = dL_dsplat + (size_t)(uint32_t)__builtin_amdgcn_readfirstlane(__float_as_uint(bi.y)) * GSR_GRAD_WORDS;
+      if (adds) atomicAdd(grad_row + my_word, ninth ? v8 : v);
+    };
     for (int sw = 1; sw >= 0; sw--) {
       unsigned long long m = lds_mask(&s_mask[wave][sw]);
       const int room = wave_last - (b * kPairBatch + sw * 64);
       if (room <= 0) continue;
       if (room < 64) m &= (1ull << room) - 1ull;
-      while (m) {
-        const int bit = 63 - __clzll((long long)m);
-        m &= ~(1ull << bit);
-        const int j = sw * 64 + bit;
-        const int pos = b * kPairBatch + j;
-        const float4 geo = s_splat.geo[j], col = s_splat.col[j];
-        // the same subtractions and the same exponent as the forward's, per pixel
-        const float dxa = geo.x - x0f, dxb = geo.x - x1f, dy = geo.y - yf;
-        const float row = gauss_exponent_row(col.x, dy), lb_dy = geo.w * dy;
-        const float pa = gauss_exponent(geo.z, lb_dy, row, dxa), pb = gauss_exponent(geo.z, lb_dy, row, dxb);
-        float oGa = col.y * __builtin_amdgcn_exp2f(pa), oGb = col.y * __builtin_amdgcn_exp2f(pb);
-        const bool hita = (pa <= 0.0f) & (oGa >= GSR_ALPHA_MIN) & (pos < last0);
-        const bool hitb = (pb <= 0.0f) & (oGb >= GSR_ALPHA_MIN) & (pos < last1);
-        if (__ballot(hita | hitb) == 0ull) continue;
-        oGa = hita ? oGa : 0.0f;
-        oGb = hitb ? oGb : 0.0f;
-        const float alphaa = __builtin_amdgcn_fmed3f(oGa, 0.0f, GSR_ALPHA_MAX), alphab = __builtin_amdgcn_fmed3f(oGb, 0.0f, GSR_ALPHA_MAX);
-        const float inva = __builtin_amdgcn_rcpf(1.0f - alphaa), invb = __builtin_amdgcn_rcpf(1.0f - alphab);
-        T0 *= inva;
-        T1 *= invb;
-        const float2 bi = s_splat.tail[j];
-        const float da = fmaf(bi.x, b0, fmaf(col.w, g0, col.z * r0)) - behind0;
-        const float db = fmaf(bi.x, b1, fmaf(col.w, g1, col.z * r1)) - behind1;
-        const float ua = fmaf(da, T0, -(Tf_bg0 * inva)) * oGa, ub = fmaf(db, T1, -(Tf_bg1 * invb)) * oGb;
-        behind0 = fmaf(alphaa, da, behind0);
-        behind1 = fmaf(alphab, db, behind1);
-        const float wa = alphaa * T0, wb = alphab * T1;
-        // the pair's nine contributions; dy is common to the two pixels
-        const float u = ua + ub;
-        const float uxa = ua * dxa, uxb = ub * dxb;
-        const float ux = uxa + uxb;
-        const float uxx = fmaf(uxb, dxb, uxa * dxa);
-        const float uy = u * dy;
-        store_rows_addtid(red_base, u, ux, uy, uxx, ux * dy, uy * dy, fmaf(wb, r1, wa * r0), fmaf(wb, g1, wa * g0));
-        const float4 a0 = *red_lo, a1 = *red_hi;
-        float v = ((a0.x + a0.y) + (a0.z + a0.w)) + ((a1.x + a1.y) + (a1.z + a1.w));
-        float v8 = fmaf(wb, b1, wa * b0);
-        v = dpp_add<0xB1>(v); v = dpp_add<0x4E>(v); v = dpp_add<0x141>(v);
-        // (the sum is wanted by a few lanes only, and left to itself the compiler moves the last addition behind
-        // their branch, where it cannot be part of the cross-lane instruction any more: three instructions for one)
-        asm volatile("" : "+v"(v));
-        v8 = sum_into_last_row(v8);
-        // the row's address as a scalar (every lane holds the same index), the lane's word as a constant offset
-        float* const grad_row = dL_dsplat + (size_t)(uint32_t)__builtin_amdgcn_readfirstlane(__float_as_uint(bi.y)) * GSR_GRAD_WORDS;
-        if (adds) atomicAdd(grad_row + my_word, ninth ? v8 : v);
+      if (b * kPairBatch + sw * 64 + 64 <= wave_first_end) {
+        while (m) {
+          const int bit = 63 - __clzll((long long)m);
+          m &= ~(1ull << bit);
+          turn(sw * 64 + bit, std::false_type{});
+        }
+      } else {
+        while (m) {
+          const int bit = 63 - __clzll((long long)m);
+          m &= ~(1ull << bit);
+          turn(sw * 64 + bit, std::true_type{});
+        }
       }
     }
   }
