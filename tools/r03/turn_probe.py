@@ -1,6 +1,7 @@
 #!/usr/bin/env python3
 """What the (wave, splat) turns of the blend backward come to, counted by a library built with
--DGSR_EXPERIMENT_COUNT (GSR_HIP_LIB points at it):   python3 tools/r03/turn_probe.py c3 c3w c5"""
+-DGSR_EXPERIMENT_COUNT from blend.hip with tools/experiments/blend_bwd_turn_counters.patch applied (GSR_HIP_LIB points
+at it):   python3 tools/r03/turn_probe.py c3 c3w c5"""
 import ctypes as C
 import math
 import os
