@@ -158,7 +158,12 @@ __device__ __forceinline__ void fill_my_share(const ShareFill& f, unsigned group
   if (f.vecs == 0) return;
   const size_t first = (size_t)group * f.share;
   const size_t end = first + f.share < f.vecs ? first + f.share : f.vecs;
-  for (size_t i = first + threadIdx.x; i < end; i += blockDim.x) f.at[i] = make_uint4(0u, 0u, 0u, 0u);
+  // Nontemporal stores: the zeros are not wanted in the L2, where the walk's gathered records live (as ordinary
+  // stores they cost the backward 7 us of 236 at 1M Gaussians and 90 us of 540 at 6M, and the kernel that later
+  // writes gradient rows into the cleared memory a quarter of its time).
+  typedef uint32_t u4 __attribute__((ext_vector_type(4)));
+  const u4 zero = {0u, 0u, 0u, 0u};
+  for (size_t i = first + threadIdx.x; i < end; i += blockDim.x) __builtin_nontemporal_store(zero, reinterpret_cast<u4*>(f.at) + i);
 }
 
 // Depth segments of long tile walks.  A tile's backward walk is serial (every step needs the transmittance

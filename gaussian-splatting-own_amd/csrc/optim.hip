@@ -22,7 +22,14 @@ namespace {
 
 constexpr int kBlock = 256;
 constexpr int kPerThread = 4;                    // one 16-byte access per array
-constexpr int kPerBlock = kBlock * kPerThread;
+// 16-byte accesses per array and thread, a block's width apart, all of a thread's loads ahead of its arithmetic; and
+// every access nontemporal: each element is touched once per step, so nothing is gained by keeping it in the L2.
+// 1M Gaussians (59M elements): one round with ordinary accesses 332 us, nontemporal 317, two rounds 304, three 299,
+// four 302.
+constexpr int kRounds = 3;
+constexpr int kPerBlock = kBlock * kPerThread * kRounds;
+#define GSR_LD(p) __builtin_nontemporal_load(p)
+#define GSR_ST(p, v) __builtin_nontemporal_store(v, p)
 
 struct AdamTensors {
   GsrAdamTensor t[GSR_ADAM_MAX_TENSORS];
@@ -46,22 +53,38 @@ __global__ void __launch_bounds__(kBlock) adam_kernel(AdamTensors a, float w1, f
   int k = 0;
   while (k + 1 < a.count && blockIdx.x >= a.first_block[k + 1]) k++;
   const GsrAdamTensor t = a.t[k];
-  const size_t base = (size_t)(blockIdx.x - a.first_block[k]) * kPerBlock + (size_t)threadIdx.x * kPerThread;
-  if (base >= t.n) return;
+  const size_t block_base = (size_t)(blockIdx.x - a.first_block[k]) * kPerBlock + (size_t)threadIdx.x * kPerThread;
   const float step_size = t.lr / bc1;
-  if (base + kPerThread <= t.n && t.vec4) {
-    float4 p = *reinterpret_cast<float4*>(t.param + base);
-    const float4 g = *reinterpret_cast<const float4*>(t.grad + base);
-    float4 m = *reinterpret_cast<float4*>(t.exp_avg + base);
-    float4 v = *reinterpret_cast<float4*>(t.exp_avg_sq + base);
-    adam_update(p.x, g.x, m.x, v.x, w1, b2, w2, step_size, inv_bc2_sqrt, eps, grad_scale);
-    adam_update(p.y, g.y, m.y, v.y, w1, b2, w2, step_size, inv_bc2_sqrt, eps, grad_scale);
-    adam_update(p.z, g.z, m.z, v.z, w1, b2, w2, step_size, inv_bc2_sqrt, eps, grad_scale);
-    adam_update(p.w, g.w, m.w, v.w, w1, b2, w2, step_size, inv_bc2_sqrt, eps, grad_scale);
-    *reinterpret_cast<float4*>(t.param + base) = p;
-    *reinterpret_cast<float4*>(t.exp_avg + base) = m;
-    *reinterpret_cast<float4*>(t.exp_avg_sq + base) = v;
-  } else {
+  if (t.vec4 && block_base - (size_t)threadIdx.x * kPerThread + kPerBlock <= t.n) {
+    // a whole block of vector accesses: all loads of the thread's rounds first
+    typedef float f4 __attribute__((ext_vector_type(4)));
+    f4 p[kRounds], g[kRounds], m[kRounds], v[kRounds];
+#pragma unroll
+    for (int r = 0; r < kRounds; r++) {
+      const size_t base = block_base + (size_t)r * kBlock * kPerThread;
+      p[r] = GSR_LD(reinterpret_cast<f4*>(t.param + base));
+      g[r] = GSR_LD(reinterpret_cast<const f4*>(t.grad + base));
+      m[r] = GSR_LD(reinterpret_cast<f4*>(t.exp_avg + base));
+      v[r] = GSR_LD(reinterpret_cast<f4*>(t.exp_avg_sq + base));
+    }
+#pragma unroll
+    for (int r = 0; r < kRounds; r++) {
+      const size_t base = block_base + (size_t)r * kBlock * kPerThread;
+      float px = p[r].x, py = p[r].y, pz = p[r].z, pw = p[r].w, mx = m[r].x, my = m[r].y, mz = m[r].z, mw = m[r].w;
+      float vx = v[r].x, vy = v[r].y, vz = v[r].z, vw = v[r].w;
+      adam_update(px, g[r].x, mx, vx, w1, b2, w2, step_size, inv_bc2_sqrt, eps, grad_scale);
+      adam_update(py, g[r].y, my, vy, w1, b2, w2, step_size, inv_bc2_sqrt, eps, grad_scale);
+      adam_update(pz, g[r].z, mz, vz, w1, b2, w2, step_size, inv_bc2_sqrt, eps, grad_scale);
+      adam_update(pw, g[r].w, mw, vw, w1, b2, w2, step_size, inv_bc2_sqrt, eps, grad_scale);
+      const f4 po = {px, py, pz, pw}, mo = {mx, my, mz, mw}, vo = {vx, vy, vz, vw};
+      GSR_ST(reinterpret_cast<f4*>(t.param + base), po);
+      GSR_ST(reinterpret_cast<f4*>(t.exp_avg + base), mo);
+      GSR_ST(reinterpret_cast<f4*>(t.exp_avg_sq + base), vo);
+    }
+    return;
+  }
+  for (int r = 0; r < kRounds; r++) {
+    const size_t base = block_base + (size_t)r * kBlock * kPerThread;
     for (size_t i = base; i < base + kPerThread && i < t.n; i++) {
       float p = t.param[i], m = t.exp_avg[i], v = t.exp_avg_sq[i];
       adam_update(p, t.grad[i], m, v, w1, b2, w2, step_size, inv_bc2_sqrt, eps, grad_scale);

@@ -374,7 +374,13 @@ __global__ void __launch_bounds__(kBlock) preprocess_fwd_kernel(FwdArgs a) {
     for (int j = 0; j < 4; j++) {
       const int r = 16 * j + (lane >> 2);
       const uint4 v = s_rec[wave][r * kRecPitch + (lane & 3)];
-      if (first + r < a.P) out[64 * j] = v;
+      // (nontemporal: the records are next read by the blend kernels, three launches on, by gathers that find little
+      // of 64 MB in the L2 anyway; as ordinary stores they cost this kernel 7 us of 72 at 1M Gaussians.  The same hint
+      // on the kernel's loads makes it half as slow again: a lane's 192-byte row arrives 16 bytes at a time, and the
+      // other pieces of a line must wait for it in the cache.)
+      typedef uint32_t u4 __attribute__((ext_vector_type(4)));
+      const u4 vv = {v.x, v.y, v.z, v.w};
+      if (first + r < a.P) __builtin_nontemporal_store(vv, reinterpret_cast<u4*>(out + 64 * j));
     }
   }
   // list sizes of the binning (tile instances, supercell entries, cell entries, visible Gaussians):
