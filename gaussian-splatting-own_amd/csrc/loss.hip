@@ -160,6 +160,9 @@ __global__ void __launch_bounds__(256, GSR_LOSS_FWD_PER_CU) loss_fwd_kernel(int 
     // (the 336 tasks are a round of 256 and a round of 80, which leaves two waves idle; a quarter of the tasks to every
     // wave, 64 + 20, keeps all four busy and is slower, 57.5 -> 60.3 us at 1080p: four partly filled rounds issue more;
     // letting the second round fall to waves 2 and 3 on every other tile, so that no SIMD always has it: no change)
+    // (the horizontal pass at raised wave priority: of a CU's workgroups the ones in this pass are the ones whose
+    // loads are still to be asked for; forward 57.4 -> 56.9 us, backward 41.5 -> 40.0 us at 1080p)
+    __builtin_amdgcn_s_setprio(2);
     for (int k = threadIdx.x; k < kHTasks; k += 256) {
       const int r = k / (kTX / kOut), q = (k % (kTX / kOut)) * kOut;
       float a[kNeed], b[kNeed], o[4][kOut];
@@ -185,6 +188,7 @@ __global__ void __launch_bounds__(256, GSR_LOSS_FWD_PER_CU) loss_fwd_kernel(int 
       for (int m = 0; m < 4; m++)
         *reinterpret_cast<float4*>(&hm[m][r * kTX + q]) = make_float4(o[m][0], o[m][1], o[m][2], o[m][3]);
     }
+    __builtin_amdgcn_s_setprio(0);
     __syncthreads();
 
     // this thread's own pixels of both images, for the L1 term
@@ -313,6 +317,7 @@ __global__ void __launch_bounds__(256, GSR_LOSS_BWD_PER_CU) loss_bwd_kernel(int 
       xs[j] = in ? img[o] : 0.f;
       ys[j] = in ? gt[o] : 0.f;
     }
+    __builtin_amdgcn_s_setprio(2);      // as in the forward
     for (int k = threadIdx.x; k < kHTasks; k += 256) {
       const int r = k / (kTX / kOut), q = (k % (kTX / kOut)) * kOut;
 #pragma unroll
@@ -329,6 +334,7 @@ __global__ void __launch_bounds__(256, GSR_LOSS_BWD_PER_CU) loss_bwd_kernel(int 
         *reinterpret_cast<float4*>(&hm[m][r * kTX + q]) = make_float4(o[0], o[1], o[2], o[3]);
       }
     }
+    __builtin_amdgcn_s_setprio(0);
     __syncthreads();
     float acc[3][kOut];
 #pragma unroll
